@@ -1,0 +1,259 @@
+"""Test-side readers for iteres' input and output FILE FORMATS, in plain Python.
+
+Independent of the product's C host code on purpose: the oracle tests go
+golden input files -> (this module) -> oracle/liboracle.so -> compare with the
+reference's golden output files, so a bug in the product's parsers cannot hide
+behind a matching bug here.
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import re
+import struct
+import zlib
+
+import numpy as np
+
+
+def open_maybe_gz(path, mode="rt"):
+    if os.path.exists(path):
+        return open(path, mode)
+    return gzip.open(path + ".gz", mode)
+
+
+def read_bytes(path):
+    with open_maybe_gz(path, "rb") as f:
+        return f.read()
+
+
+def materialise(src_dir, name, dst_dir):
+    """Copy (gunzip if stored gzipped) a golden input file into dst_dir; returns its path."""
+    dst = os.path.join(dst_dir, name)
+    with open(dst, "wb") as f:
+        f.write(read_bytes(os.path.join(src_dir, name)))
+    return dst
+
+
+_NUM = re.compile(r"\s*([+-]?)(0[xX][0-9a-fA-F]+|0[0-7]*|[1-9][0-9]*)")
+
+
+def strtol0(s: str) -> int:
+    """C strtol(s, NULL, 0): optional sign, 0x.. hex, 0.. octal, else decimal; 0 when nothing parses."""
+    m = _NUM.match(s)
+    if not m:
+        return 0
+    sign, body = m.groups()
+    if body.lower().startswith("0x"):
+        v = int(body, 16)
+    elif body.startswith("0") and len(body) > 1:
+        v = int(body, 8)
+    else:
+        v = int(body)
+    v = -v if sign == "-" else v
+    return max(min(v, 2**63 - 1), -2**63)
+
+
+def u32(v: int) -> int:
+    return v & 0xFFFFFFFF
+
+
+def read_sizes(path):
+    """cuskent/obscure.c:139-150 hashNameIntFile: later duplicates shadow earlier ones."""
+    out = {}
+    with open_maybe_gz(path) as f:
+        for line in f:
+            if not line.strip() or line.lstrip().startswith("#"):
+                continue
+            w = line.split()
+            out[w[0]] = int(w[1])
+    return out
+
+
+def read_rmsk(path):
+    """Rows as the reference parses them (generic.c:1587-1607): whitespace-split, '#' lines skipped."""
+    rows = []
+    with open_maybe_gz(path) as f:
+        for line in f:
+            if line.startswith("#") or not line.strip():
+                continue
+            w = line.split()
+            strand = w[9][0]
+            rows.append({
+                "chr": w[5], "start": u32(strtol0(w[6])), "end": u32(strtol0(w[7])), "strand": strand,
+                "name": w[10], "cname": w[11], "fname": w[12],
+                "cons_start": u32(strtol0(w[13] if strand == "+" else w[15])), "cons_end": u32(strtol0(w[14])),
+                "cols": w,
+            })
+    return rows
+
+
+FUNMAP = 4
+_CIG_ADV = set("MDN")     # samtools 0.1.18 bam_calend: cussamtools/bam.c:17-27
+
+
+def _cigar_tmpend(pos, ops, l_qseq):
+    if not ops:
+        return pos + l_qseq
+    e = pos
+    for op, ln in ops:
+        if op in _CIG_ADV:
+            e += ln
+    return e
+
+
+def _wrap_i32(v):
+    return ((int(v) + 2**31) % 2**32) - 2**31
+
+
+def read_sam(path):
+    """SAM text -> core fields, following samtools-0.1.18's text parser where it matters here:
+    a mapped record whose CIGAR is '*' is flagged unmapped (cussamtools/bam_import.c sam_read1)."""
+    header, idx = [], {}
+    recs = {k: [] for k in ("tid", "pos", "tmpend", "mapq", "flag", "mpos", "isize", "qname")}
+    with open_maybe_gz(path) as f:
+        for line in f:
+            if line.startswith("@"):
+                if line.startswith("@SQ"):
+                    d = dict(x.split(":", 1) for x in line.rstrip("\n").split("\t")[1:])
+                    idx[d["SN"]] = len(header)
+                    header.append((d["SN"], int(d["LN"])))
+                continue
+            w = line.rstrip("\n").split("\t")
+            flag = int(w[1])
+            tid = idx.get(w[2], -1)
+            pos = int(w[3]) - 1
+            ops = [] if w[5] == "*" else [(m.group(2), int(m.group(1))) for m in re.finditer(r"(\d+)([MIDNSHP=X])", w[5])]
+            if not ops and not (flag & FUNMAP):
+                flag |= FUNMAP
+            l_qseq = 0 if w[9] == "*" else len(w[9])
+            recs["tid"].append(tid)
+            recs["pos"].append(pos)
+            recs["tmpend"].append(_wrap_i32(_cigar_tmpend(pos, ops, l_qseq)))
+            recs["mapq"].append(int(w[4]))
+            recs["flag"].append(flag)
+            recs["mpos"].append(int(w[7]) - 1)
+            recs["isize"].append(int(w[8]))
+            recs["qname"].append(w[0])
+    return header, _to_arrays(recs)
+
+
+def _to_arrays(recs):
+    return {"tid": np.array(recs["tid"], np.int32), "pos": np.array(recs["pos"], np.int32),
+            "tmpend": np.array(recs["tmpend"], np.int32), "mapq": np.array(recs["mapq"], np.uint8),
+            "flag": np.array(recs["flag"], np.uint16), "mpos": np.array(recs["mpos"], np.int32),
+            "isize": np.array(recs["isize"], np.int32), "qname": recs["qname"]}
+
+
+def bgzf_decompress(data: bytes) -> bytes:
+    out, off = [], 0
+    while off < len(data):
+        d = zlib.decompressobj(31)
+        out.append(d.decompress(data[off:]))
+        off = len(data) - len(d.unused_data)
+    return b"".join(out)
+
+
+def read_bam(path):
+    raw = bgzf_decompress(read_bytes(path))
+    assert raw[:4] == b"BAM\1"
+    l_text, = struct.unpack_from("<i", raw, 4)
+    off = 8 + l_text
+    n_ref, = struct.unpack_from("<i", raw, off)
+    off += 4
+    header = []
+    for _ in range(n_ref):
+        l_name, = struct.unpack_from("<i", raw, off)
+        name = raw[off + 4: off + 4 + l_name - 1].decode()
+        ln, = struct.unpack_from("<i", raw, off + 4 + l_name)
+        header.append((name, ln))
+        off += 8 + l_name
+    recs = {k: [] for k in ("tid", "pos", "tmpend", "mapq", "flag", "mpos", "isize", "qname")}
+    cig_ops = "MIDNSHP=X"
+    while off + 4 <= len(raw):
+        bs, = struct.unpack_from("<i", raw, off)
+        tid, pos, bmn, fnc, l_seq, mtid, mpos, isize = struct.unpack_from("<iiIIiiii", raw, off + 4)
+        l_qn = bmn & 0xFF
+        mapq = (bmn >> 8) & 0xFF
+        flag = fnc >> 16
+        n_cig = fnc & 0xFFFF
+        p = off + 36
+        qname = raw[p: p + l_qn - 1].decode()
+        p += l_qn
+        ops = []
+        for k in range(n_cig):
+            c, = struct.unpack_from("<I", raw, p + 4 * k)
+            ops.append((cig_ops[c & 0xF] if (c & 0xF) < 9 else "?", c >> 4))
+        recs["tid"].append(tid)
+        recs["pos"].append(pos)
+        recs["tmpend"].append(_wrap_i32(_cigar_tmpend(pos, ops, l_seq)))
+        recs["mapq"].append(mapq)
+        recs["flag"].append(flag)
+        recs["mpos"].append(mpos)
+        recs["isize"].append(isize)
+        recs["qname"].append(qname)
+        off += 4 + bs
+    return header, _to_arrays(recs)
+
+
+# ------------------------------------------------------------------------------ outputs of the reference
+
+def parse_stat(path):
+    with open_maybe_gz(path) as f:
+        lines = f.read().split("\n")
+    return lines[0].split("\t"), [l.split("\t") for l in lines[1:] if l]
+
+
+def parse_wig(path):
+    out, cur = {}, None
+    order = []
+    with open_maybe_gz(path) as f:
+        for line in f:
+            if line.startswith("fixedStep"):
+                name = line.split("chrom=")[1].split(" start=")[0]
+                cur = []
+                out[name] = cur
+                order.append(name)
+            elif line.strip():
+                cur.append(int(line))
+    return {k: np.array(v, np.uint32) for k, v in out.items()}, order
+
+
+def parse_report(path):
+    vals = []
+    with open_maybe_gz(path) as f:
+        for line in f:
+            vals.append(int(line.rstrip("\n").rsplit(": ", 1)[1]))
+    # report order (generic.c:55-68): cnt[0], cnt[6], cnt[7], cnt[11], cnt[12], cnt[9], cnt[10]
+    return dict(zip((0, 6, 7, 11, 12, 9, 10), vals))
+
+
+def parse_loci(path):
+    with open_maybe_gz(path) as f:
+        lines = f.read().split("\n")
+    return lines[0].split("\t"), [l.split("\t") for l in lines[1:] if l]
+
+
+# ------------------------------------------------------------------------------ kent hash iteration order
+
+def kent_hash_string(s: str) -> int:
+    """cuskent/hash.c:41-53 (chars are signed on x86-64)."""
+    r = 0
+    for b in s.encode():
+        c = b - 256 if b >= 128 else b
+        r = (r + ((r << 3) & 0xFFFFFFFF) + c) & 0xFFFFFFFF
+    return r
+
+
+def kent_hash_order(names_in_insertion_order, power=12):
+    """Iteration order of hashFirst/hashNext (cuskent/hash.c:511-552) over a hash built by hashAdd in
+    the given order, starting at 2**power buckets and doubling when elCount > size (hash.c:136-140,
+    374-410; the resize preserves the newest-first order inside a bucket)."""
+    size = 1 << power
+    n = 0
+    for _ in names_in_insertion_order:
+        n += 1
+        if n > size:
+            size *= 2
+    keyed = [((kent_hash_string(nm) & (size - 1)), -i, nm) for i, nm in enumerate(names_in_insertion_order)]
+    return [nm for _, _, nm in sorted(keyed)]

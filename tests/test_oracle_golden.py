@@ -111,7 +111,7 @@ def test_find_order_quirk():
     n = len(rows)
     ot.add_rows([0] * n, [r[0] for r in rows], [r[1] for r in rows], [0] * n, [50] * n, [0] * n, [0] * n, [0] * n)
     assert list(ot.find(0, 131050, 131150)) == [0, 1, 4, 2, 3, 5]
-    assert list(ot.find(0, 131077, 131078)) == [0, 1, 2, 3]
+    assert list(ot.find(0, 131077, 131078)) == [0, 1, 3]
     assert list(ot.find(0, -5, 130001)) == [4]          # start clipped to 0 (binRange.c:204)
     assert list(ot.find(0, 131300, 700000)) == [2]      # end clipped to chrom size (binRange.c:205)
     assert list(ot.find(0, 500, 500)) == []

@@ -1,0 +1,188 @@
+/* iteres_amd.h — C ABI of the MI355X (gfx950) engine for iteres' one hot path:
+ *
+ *     BAM record -> RepeatMasker-interval overlap classification -> per-repName / repFamily /
+ *     repClass read counters, per-base consensus coverage (iteres stat) and per-locus read
+ *     counts (iteres filter).
+ *
+ * The reference (lidaof/iteres, /root/reference) has no library or FFI surface: the path is
+ * two static loops inside the program. This header is therefore the seam a maintainer would cut
+ * INSIDE the reference: every entry point names the reference code it stands in for (paths
+ * relative to /root/reference). INTEGRATION.md shows the calls a patched generic.c / stat.c /
+ * filter.c would make.
+ *
+ * Conventions: plain C, no global state, every function returns ITX_OK (0) or a negative ITX_E_*
+ * code; itx_last_error() gives a thread-local message. One submitting thread per engine.
+ * All "host" pointers are ordinary host memory; "device" pointers are HIP device memory on the
+ * engine's GPU. There is no CPU fallback: every call that needs the GPU fails with
+ * ITX_E_NO_DEVICE when none is usable.
+ */
+#ifndef ITERES_AMD_H
+#define ITERES_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITX_OK 0
+#define ITX_E_ARG (-1)        /* bad argument */
+#define ITX_E_RANGE (-2)      /* a table row is outside its chromosome: what binKeeperAdd errAborts on (cuskent/binRange.c:176-178) */
+#define ITX_E_NO_DEVICE (-3)  /* no usable gfx950 device / HIP runtime error */
+#define ITX_E_NOMEM (-4)
+#define ITX_E_STATE (-5)      /* call order violated (e.g. submit before set_tidmap) */
+#define ITX_E_LIMIT (-6)      /* a size exceeds what the device layout encodes */
+
+const char *itx_last_error(void);
+/* ABI version of this header: major*1000 + minor. */
+int itx_abi_version(void);
+/* Number of visible HIP devices, or a negative ITX_E_* code. Does not create a context. */
+int itx_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * The repeat table: replaces `struct hash *hashRmsk` (per-chromosome binKeeper of struct rmsk,
+ * generic.h:7-15, built by rmsk2binKeeperHash generic.c:1578-1626) together with the per-row
+ * links to hashRep / hashFam / hashCla entries (generic.c:1631-1693) and the repeat-size lookup
+ * (generic.c:1647).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct itx_table itx_table;
+
+/* One rmsk.txt row as generic.c:1594-1607 parses it. `chrom` indexes chrom_size[]; rep/fam/cla
+ * are dense ids of the row's OWN repName / repFamily / repClass strings (repName -> family is
+ * not functional in rmsk, so the ids come from the row). Rows are given in FILE order: the
+ * order decides ties exactly as binKeeper's insertion order does (cuskent/binRange.c:185,209-225). */
+typedef struct itx_row {
+    int32_t  chrom;
+    uint32_t start, end;            /* genoStart, genoEnd                        (generic.c:1602-1603) */
+    uint32_t cons_start, cons_end;  /* consensus_start / consensus_end           (generic.c:1596-1601) */
+    uint32_t rep, fam, cla;
+} itx_row;
+
+/* chrom_size[c] = value from the chrom-size file; rep_len[r] = consensus length from the
+ * repeat-size file or 0 (generic.c:1647). Fails with ITX_E_RANGE on a row binKeeperAdd would
+ * abort on; *bad_row (optional) receives its index. device = HIP device ordinal. */
+int itx_table_create(const itx_row *rows, size_t n_rows, const int64_t *chrom_size, int n_chrom,
+                     const uint32_t *rep_len, uint32_t n_rep, uint32_t n_fam, uint32_t n_cla,
+                     int device, itx_table **out, size_t *bad_row);
+void itx_table_destroy(itx_table *t);
+
+typedef struct itx_table_info {
+    uint64_t n_rows, n_rep, n_fam, n_cla;
+    uint64_t cov_len;      /* sum of rep_len: length of the concatenated coverage vectors          */
+    uint64_t n_u64;        /* elements of the u64 accumulator block (see itx_engine_create)        */
+    uint64_t n_u32;        /* elements of the u32 accumulator block                                */
+    uint64_t table_bytes;  /* device bytes the table occupies                                      */
+    int32_t  n_chrom, bin_shift, device, reserved;
+} itx_table_info;
+int itx_table_get_info(const itx_table *t, itx_table_info *out);
+/* off[r] = start of repName r inside cov/cov_uniq; off[n_rep] = cov_len. */
+int itx_table_cov_offsets(const itx_table *t, uint64_t *off);
+
+/* ---------------------------------------------------------------------------------------------
+ * The engine: replaces the body of the record loop, generic.c:748-1036 (stat copy) ==
+ * generic.c:385-697 (filter copy): read-end / mapped / used counters, coordinate derivation,
+ * binKeeperFind + best-hit rule (generic.c:945-970), and the accumulate step
+ * (generic.c:983-1032). Host-side, order-dependent features stay with the caller: -R dedup
+ * (generic.c:907-919), bed emission (925-936), the XA/NM veto (972-982), qname lists (662-666).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct itx_engine itx_engine;
+
+typedef struct itx_params {
+    uint32_t mapq_min;             /* -Q  unique-read MAPQ threshold           (stat.c:49)  */
+    float    min_cov;              /* -c / -g coverage threshold               (stat.c:50)  */
+    uint32_t extension;            /* -E  0 = none                             (stat.c:61)  */
+    uint32_t isize_max;            /* -I                                       (stat.c:62)  */
+    int32_t  treat_pe_as_se;       /* -T                                       (stat.c:55)  */
+    int32_t  discard_half_mapped;  /* -D                                       (stat.c:56)  */
+    int32_t  mode;                 /* ITX_MODE_STAT: counters + coverage; ITX_MODE_FILTER: per-locus counts */
+    int32_t  accum;                /* ITX_ACCUM_*: how the device accumulates (same results)            */
+} itx_params;
+#define ITX_MODE_STAT 0
+#define ITX_MODE_FILTER 1
+#define ITX_ACCUM_DEFAULT 0
+#define ITX_ACCUM_ATOMIC 1        /* global atomics straight from the classify kernel                  */
+#define ITX_ACCUM_PARTITION 2     /* key emit -> radix partition -> LDS histograms (no scattered atomics) */
+
+/* Record batch, structure of arrays. One element per BAM record, in file order:
+ *   tid, pos            bam1_core_t.tid / .pos                       (cussamtools/bam.h:169-177)
+ *   tmpend              n_cigar ? bam_calend(core, cigar) : pos + l_qseq          (generic.c:820)
+ *   mapq                bam1_core_t.qual
+ *   flag5               bit0 PAIRED(0x1) bit1 UNMAP(0x4) bit2 MUNMAP(0x8) bit3 REVERSE(0x10) bit4 READ1(0x40)
+ *   mpos, isize         bam1_core_t.mpos / .isize; both may be NULL when no record of the batch
+ *                       has PAIRED set (then they are never read). */
+typedef struct itx_batch {
+    const int32_t *tid, *pos, *tmpend;
+    const uint8_t *mapq, *flag5;
+    const int32_t *mpos, *isize;
+} itx_batch;
+#define ITX_FLAG5(bamflag) ((uint8_t)((((bamflag) & 0x1) ? 1 : 0) | (((bamflag) & 0x4) ? 2 : 0) | (((bamflag) & 0x8) ? 4 : 0) | \
+                                      (((bamflag) & 0x10) ? 8 : 0) | (((bamflag) & 0x40) ? 16 : 0)))
+
+/* batch_capacity = largest n a single submit may carry. u64_accum / u32_accum: optional
+ * caller-owned DEVICE buffers of itx_table_info.n_u64 / n_u32 elements (zeroed by the caller) to
+ * accumulate into — this is what a multi-GPU driver all-reduces (sum) across ranks before
+ * itx_engine_finish; pass NULL to let the engine own them. */
+int itx_engine_create(const itx_table *t, const itx_params *p, size_t batch_capacity,
+                      void *u64_accum, void *u32_accum, itx_engine **out);
+void itx_engine_destroy(itx_engine *e);
+
+/* tid2chrom[tid] for the BAM header in use: index into chrom_size[], or -1 when the (possibly
+ * -C renamed) reference name is not in the chrom-size file or its size is 2 (generic.c:793-801),
+ * or -2 when -C drops it (generic.c:783-784). Call again when the next BAM of a list starts. */
+int itx_engine_set_tidmap(itx_engine *e, const int32_t *tid2chrom, int n_tid);
+
+/* Pinned double buffers (2 slots): the host decoder fills slot s while slot 1-s is in flight. */
+typedef struct itx_staging {
+    int32_t *tid, *pos, *tmpend;
+    uint8_t *mapq, *flag5;
+    int32_t *mpos, *isize;
+    int32_t *hit_row;              /* filled by the device when submit_slot(want_hits != 0) */
+    size_t capacity;
+} itx_staging;
+int itx_engine_staging(itx_engine *e, int slot, itx_staging *out);
+/* Asynchronous: H2D copies + kernels on the slot's stream. has_paired = 0 promises that no record
+ * has PAIRED set (mpos/isize are then not copied). want_hits: write back per record the index of
+ * the chosen table row (as passed to itx_table_create) or -1 into staging.hit_row. */
+int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has_paired, int want_hits);
+int itx_engine_wait_slot(itx_engine *e, int slot);
+
+/* Same work on a batch that is ALREADY in device memory (pointers in `b` are device pointers),
+ * enqueued on `stream` (a hipStream_t, NULL = the null stream). d_hit_row: optional device
+ * int32[n] for the chosen rows. Returns after enqueueing. */
+int itx_engine_submit_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
+/* Classification only (no accumulation): cuskent/binRange.c:196-227 + generic.c:950-970 per record. */
+int itx_engine_classify_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
+int itx_engine_sync(itx_engine *e);
+/* Zero every accumulator (also caller-owned ones). */
+int itx_engine_reset(itx_engine *e);
+
+/* What the loop leaves behind for the writers (generic.c:53-113, 1709-1746). Any pointer may be
+ * NULL. cnt[13] as generic.c:1048-1060 (cnt[8] and cnt[12] stay 0 here: -R and the XA veto are
+ * the caller's); rep/fam/cla_cnt: [0,n) all reads, [n,2n) reads with MAPQ >= mapq_min;
+ * cov/cov_uniq: bp_total / bp_total_unique of every repName, concatenated per
+ * itx_table_cov_offsets; locus_cnt[row]: slCount(ss->sl) per table row (filter mode). */
+typedef struct itx_result {
+    uint64_t *cnt;
+    uint64_t *rep_cnt, *fam_cnt, *cla_cnt;
+    uint32_t *cov, *cov_uniq;
+    uint32_t *locus_cnt;
+} itx_result;
+/* Drains all streams, turns the raw accumulators into the result arrays on the device and copies
+ * them to the host pointers of `out`. The raw accumulators are left untouched, so more batches may
+ * follow and finish may be called again. */
+int itx_engine_finish(itx_engine *e, const itx_result *out);
+
+/* Device time spent in the engine's kernels since the last reset, from HIP events recorded on the
+ * submitting stream around each submit_device/submit_slot (milliseconds), and the number of
+ * records classified. */
+typedef struct itx_stats {
+    double kernel_ms;
+    uint64_t records, hits;
+    uint64_t reserved[5];
+} itx_stats;
+int itx_engine_get_stats(itx_engine *e, itx_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

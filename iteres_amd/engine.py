@@ -1,0 +1,254 @@
+"""ctypes binding of include/iteres_amd.h (libiteres_amd.so) for the test-suite, bench.py and smoke().
+
+This is plumbing above the C ABI, not a second implementation: every call lands in the HIP engine.
+If the shared library is missing or no GPU is usable the calls raise — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libiteres_amd.so")
+
+MODE_STAT, MODE_FILTER = 0, 1
+ACCUM_DEFAULT, ACCUM_ATOMIC, ACCUM_PARTITION = 0, 1, 2
+
+EXPORTS = [
+    "itx_last_error", "itx_abi_version", "itx_device_count", "itx_table_create", "itx_table_destroy",
+    "itx_table_get_info", "itx_table_cov_offsets", "itx_engine_create", "itx_engine_destroy", "itx_engine_set_tidmap",
+    "itx_engine_staging", "itx_engine_submit_slot", "itx_engine_wait_slot", "itx_engine_submit_device",
+    "itx_engine_classify_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
+]
+
+
+class ItxError(RuntimeError):
+    pass
+
+
+class Row(C.Structure):
+    _fields_ = [("chrom", C.c_int32), ("start", C.c_uint32), ("end", C.c_uint32), ("cons_start", C.c_uint32),
+                ("cons_end", C.c_uint32), ("rep", C.c_uint32), ("fam", C.c_uint32), ("cla", C.c_uint32)]
+
+
+ROW_DTYPE = np.dtype([("chrom", "<i4"), ("start", "<u4"), ("end", "<u4"), ("cons_start", "<u4"), ("cons_end", "<u4"),
+                      ("rep", "<u4"), ("fam", "<u4"), ("cla", "<u4")])
+assert ROW_DTYPE.itemsize == C.sizeof(Row) == 32
+
+
+class TableInfo(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_rep", C.c_uint64), ("n_fam", C.c_uint64), ("n_cla", C.c_uint64),
+                ("cov_len", C.c_uint64), ("n_u64", C.c_uint64), ("n_u32", C.c_uint64), ("table_bytes", C.c_uint64),
+                ("n_chrom", C.c_int32), ("bin_shift", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("mapq_min", C.c_uint32), ("min_cov", C.c_float), ("extension", C.c_uint32), ("isize_max", C.c_uint32),
+                ("treat_pe_as_se", C.c_int32), ("discard_half_mapped", C.c_int32), ("mode", C.c_int32), ("accum", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("tid", "pos", "tmpend", "mapq", "flag5", "mpos", "isize")]
+
+
+class Staging(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("tid", "pos", "tmpend", "mapq", "flag5", "mpos", "isize", "hit_row")] + [("capacity", C.c_size_t)]
+
+
+class Result(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq", "locus_cnt")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("records", C.c_uint64), ("hits", C.c_uint64), ("reserved", C.c_uint64 * 5)]
+
+
+_lib = None
+
+
+def load():
+    """Loads the in-tree shared library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ItxError(f"{LIB_PATH} is missing: build it with `python -m iteres_amd.build` (hipcc, gfx950)")
+    L = C.CDLL(LIB_PATH)
+    L.itx_last_error.restype = C.c_char_p
+    L.itx_table_create.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.itx_table_destroy.argtypes = [C.c_void_p]
+    L.itx_table_destroy.restype = None
+    L.itx_table_get_info.argtypes = [C.c_void_p, C.POINTER(TableInfo)]
+    L.itx_table_cov_offsets.argtypes = [C.c_void_p, C.c_void_p]
+    L.itx_engine_create.argtypes = [C.c_void_p, C.POINTER(Params), C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.itx_engine_destroy.argtypes = [C.c_void_p]
+    L.itx_engine_destroy.restype = None
+    L.itx_engine_set_tidmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.itx_engine_staging.argtypes = [C.c_void_p, C.c_int, C.POINTER(Staging)]
+    L.itx_engine_submit_slot.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int]
+    L.itx_engine_wait_slot.argtypes = [C.c_void_p, C.c_int]
+    L.itx_engine_submit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_void_p, C.c_void_p]
+    L.itx_engine_classify_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_void_p, C.c_void_p]
+    L.itx_engine_sync.argtypes = [C.c_void_p]
+    L.itx_engine_reset.argtypes = [C.c_void_p]
+    L.itx_engine_finish.argtypes = [C.c_void_p, C.POINTER(Result)]
+    L.itx_engine_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise ItxError(f"{what}: rc={rc}: {load().itx_last_error().decode(errors='replace')}")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def flag5(bamflag):
+    f = np.asarray(bamflag).astype(np.uint32)
+    return (((f & 0x1) != 0) * 1 + ((f & 0x4) != 0) * 2 + ((f & 0x8) != 0) * 4 + ((f & 0x10) != 0) * 8 + ((f & 0x40) != 0) * 16).astype(np.uint8)
+
+
+def make_rows(chrom, start, end, cons_start, cons_end, rep, fam, cla):
+    n = len(chrom)
+    rows = np.empty(n, ROW_DTYPE)
+    u = lambda a: (np.asarray(a).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    rows["chrom"] = np.asarray(chrom, np.int32)
+    for k, v in (("start", start), ("end", end), ("cons_start", cons_start), ("cons_end", cons_end), ("rep", rep), ("fam", fam), ("cla", cla)):
+        rows[k] = u(v)
+    return rows
+
+
+class Table:
+    def __init__(self, rows, chrom_size, rep_len, n_fam, n_cla, device=0):
+        L = load()
+        self.rows = np.ascontiguousarray(rows, ROW_DTYPE)
+        cs = np.ascontiguousarray(chrom_size, np.int64)
+        rl = np.ascontiguousarray(rep_len, np.uint32)
+        h = C.c_void_p()
+        bad = C.c_size_t(0)
+        rc = L.itx_table_create(_p(self.rows), len(self.rows), _p(cs), len(cs), _p(rl), len(rl), int(n_fam), int(n_cla), int(device),
+                                C.byref(h), C.byref(bad))
+        self.bad_row = bad.value
+        _chk(rc, "itx_table_create")
+        self._h = h
+        self.info = TableInfo()
+        _chk(L.itx_table_get_info(self._h, C.byref(self.info)), "itx_table_get_info")
+        self.cov_off = np.zeros(len(rl) + 1, np.uint64)
+        _chk(L.itx_table_cov_offsets(self._h, _p(self.cov_off)), "itx_table_cov_offsets")
+        self.n_rep, self.n_fam, self.n_cla, self.n_rows = len(rl), int(n_fam), int(n_cla), len(self.rows)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().itx_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    def __init__(self, table: Table, params: dict | None = None, batch_capacity: int = 1 << 20, u64_accum_ptr=None, u32_accum_ptr=None):
+        L = load()
+        q = dict(mapq_min=10, min_cov=0.0001, extension=150, isize_max=500, treat_pe_as_se=False, discard_half_mapped=False,
+                 filter_mode=False, accum=ACCUM_DEFAULT)
+        q.update(params or {})
+        self.params = Params(int(q["mapq_min"]), float(np.float32(q["min_cov"])), int(q["extension"]), int(q["isize_max"]),
+                             int(bool(q["treat_pe_as_se"])), int(bool(q["discard_half_mapped"])),
+                             MODE_FILTER if q.get("filter_mode") else MODE_STAT, int(q["accum"]))
+        self.table = table
+        h = C.c_void_p()
+        _chk(L.itx_engine_create(table._h, C.byref(self.params), int(batch_capacity), u64_accum_ptr, u32_accum_ptr, C.byref(h)),
+             "itx_engine_create")
+        self._h = h
+        self.capacity = int(batch_capacity)
+
+    def set_tidmap(self, tid2chrom):
+        a = np.ascontiguousarray(tid2chrom, np.int32)
+        _chk(load().itx_engine_set_tidmap(self._h, _p(a), len(a)), "itx_engine_set_tidmap")
+
+    def staging(self, slot):
+        st = Staging()
+        _chk(load().itx_engine_staging(self._h, slot, C.byref(st)), "itx_engine_staging")
+        n = st.capacity
+
+        def view(ptr, ctype, dt):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).view(dt)
+        return {"tid": view(st.tid, C.c_int32, np.int32), "pos": view(st.pos, C.c_int32, np.int32),
+                "tmpend": view(st.tmpend, C.c_int32, np.int32), "mapq": view(st.mapq, C.c_uint8, np.uint8),
+                "flag5": view(st.flag5, C.c_uint8, np.uint8), "mpos": view(st.mpos, C.c_int32, np.int32),
+                "isize": view(st.isize, C.c_int32, np.int32), "hit_row": view(st.hit_row, C.c_int32, np.int32)}
+
+    def submit_host(self, tid, pos, tmpend, mapq, flag5_, mpos=None, isize=None, want_hits=False):
+        """Streams host arrays through the pinned double buffers (slot ping-pong). Returns hit rows if asked."""
+        L = load()
+        n = len(tid)
+        hits = np.empty(n, np.int32) if want_hits else None
+        paired = mpos is not None and isize is not None
+        bufs = [self.staging(0), self.staging(1)]
+        pending = [None, None]
+        off, s = 0, 0
+        while off < n or any(p is not None for p in pending):
+            if pending[s] is not None:
+                _chk(L.itx_engine_wait_slot(self._h, s), "itx_engine_wait_slot")
+                a, b = pending[s]
+                if want_hits:
+                    hits[a:b] = bufs[s]["hit_row"][: b - a]
+                pending[s] = None
+            if off < n:
+                m = min(self.capacity, n - off)
+                sl = slice(off, off + m)
+                bufs[s]["tid"][:m] = tid[sl]; bufs[s]["pos"][:m] = pos[sl]; bufs[s]["tmpend"][:m] = tmpend[sl]
+                bufs[s]["mapq"][:m] = mapq[sl]; bufs[s]["flag5"][:m] = flag5_[sl]
+                if paired:
+                    bufs[s]["mpos"][:m] = mpos[sl]; bufs[s]["isize"][:m] = isize[sl]
+                _chk(L.itx_engine_submit_slot(self._h, s, m, int(paired), int(want_hits)), "itx_engine_submit_slot")
+                pending[s] = (off, off + m)
+                off += m
+            s ^= 1
+        return hits
+
+    def submit_device(self, ptrs: dict, n: int, hit_ptr=None, stream=None, classify_only=False):
+        b = Batch(*(ptrs.get(k) for k in ("tid", "pos", "tmpend", "mapq", "flag5", "mpos", "isize")))
+        fn = load().itx_engine_classify_device if classify_only else load().itx_engine_submit_device
+        _chk(fn(self._h, C.byref(b), int(n), hit_ptr, stream), "itx_engine_submit_device")
+
+    def sync(self):
+        _chk(load().itx_engine_sync(self._h), "itx_engine_sync")
+
+    def reset(self):
+        _chk(load().itx_engine_reset(self._h), "itx_engine_reset")
+
+    def finish(self):
+        t = self.table
+        res = {"cnt": np.zeros(13, np.uint64), "rep_cnt": np.zeros(2 * t.n_rep, np.uint64), "fam_cnt": np.zeros(2 * t.n_fam, np.uint64),
+               "cla_cnt": np.zeros(2 * t.n_cla, np.uint64), "cov": np.zeros(int(t.info.cov_len), np.uint32),
+               "cov_uniq": np.zeros(int(t.info.cov_len), np.uint32), "locus_cnt": np.zeros(max(t.n_rows, 1), np.uint32)}
+        r = Result(*(_p(res[k]) for k in ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq", "locus_cnt")))
+        _chk(load().itx_engine_finish(self._h, C.byref(r)), "itx_engine_finish")
+        return res
+
+    def stats(self):
+        s = Stats()
+        _chk(load().itx_engine_get_stats(self._h, C.byref(s)), "itx_engine_get_stats")
+        return {"kernel_ms": s.kernel_ms, "records": int(s.records), "hits": int(s.hits)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().itx_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -11,7 +11,9 @@
 struct ItxSlot {
     itx_staging h;        // pinned host
     itx_staging d;        // device mirrors
-    hipStream_t stream;
+    hipStream_t stream;   // copy stream of this slot (H2D in, hit rows D2H out)
+    hipEvent_t copied;    // H2D of the slot finished
+    hipEvent_t done;      // kernels of the slot finished on the compute stream
     bool busy;
 };
 
@@ -26,6 +28,8 @@ struct itx_engine {
     int32_t *d_tidmap;
     int n_tid, cap_tid;
     ItxSlot slot[2];
+    hipStream_t compute;  // every kernel of the slot path runs here, in submission order: batches never overlap
+                          // each other (the partition path's scratch and the exclusive window updates rely on it)
     bool slots_ready;
     // finalize outputs (device), allocated on first finish
     uint64_t *d_rep_out;
@@ -62,7 +66,7 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     if (!e) return ITX_E_NOMEM;
     e->t = t;
     e->p = *p;
-    if (e->p.accum == ITX_ACCUM_DEFAULT) e->p.accum = ITX_ACCUM_ATOMIC;
+    if (e->p.accum == ITX_ACCUM_DEFAULT) e->p.accum = ITX_ACCUM_PARTITION;
     if (e->p.mode == ITX_MODE_FILTER) e->p.accum = ITX_ACCUM_ATOMIC;   // per-locus counts: one aggregated atomic per run
     e->cap = batch_capacity;
     e->L = itx_accum_layout(t->n_rep, t->n_fam, t->n_cla, t->n_slots, t->n_rows);
@@ -72,6 +76,7 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     e->d_tidmap = nullptr;
     e->n_tid = e->cap_tid = 0;
     e->slots_ready = false;
+    e->compute = nullptr;
     memset(e->slot, 0, sizeof e->slot);
     e->d_rep_out = nullptr;
     e->d_cov = e->d_cov_uniq = e->d_locus_out = nullptr;
@@ -131,7 +136,10 @@ extern "C" void itx_engine_destroy(itx_engine *e)
         for (int s = 0; s < 2; s++) {
             free_staging(&e->slot[s].h, &e->slot[s].d);
             if (e->slot[s].stream) (void)hipStreamDestroy(e->slot[s].stream);
+            if (e->slot[s].copied) (void)hipEventDestroy(e->slot[s].copied);
+            if (e->slot[s].done) (void)hipEventDestroy(e->slot[s].done);
         }
+    if (e->slots_ready && e->compute) (void)hipStreamDestroy(e->compute);
     if (e->own_u64 && e->u64) (void)hipFree(e->u64);
     if (e->own_u32 && e->u32) (void)hipFree(e->u32);
     if (e->d_tidmap) (void)hipFree(e->d_tidmap);
@@ -172,9 +180,12 @@ static int ensure_slots(itx_engine *e)
 {
     if (e->slots_ready) return ITX_OK;
     const size_t n = e->cap;
+    ITX_HIP(hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking));
     for (int s = 0; s < 2; s++) {
         ItxSlot &S = e->slot[s];
         ITX_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+        ITX_HIP(hipEventCreateWithFlags(&S.copied, hipEventDisableTiming));
+        ITX_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
 #define BOTH(field, type)                                                                  \
     ITX_HIP(hipHostMalloc((void **)&S.h.field, n * sizeof(type), hipHostMallocDefault));   \
     ITX_HIP(hipMalloc((void **)&S.d.field, n * sizeof(type)));
@@ -275,8 +286,12 @@ extern "C" int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has
 #undef H2D
     ItxDevBatch B = {S.d.tid, S.d.pos, S.d.tmpend, S.d.mapq, S.d.flag5, has_paired ? S.d.mpos : nullptr,
                      has_paired ? S.d.isize : nullptr};
-    rc = run_batch(e, B, n, want_hits ? S.d.hit_row : nullptr, S.stream, true);
+    ITX_HIP(hipEventRecord(S.copied, S.stream));
+    ITX_HIP(hipStreamWaitEvent(e->compute, S.copied, 0));
+    rc = run_batch(e, B, n, want_hits ? S.d.hit_row : nullptr, e->compute, true);
     if (rc) return rc;
+    ITX_HIP(hipEventRecord(S.done, e->compute));
+    ITX_HIP(hipStreamWaitEvent(S.stream, S.done, 0));
     if (want_hits)
         ITX_HIP(hipMemcpyAsync(S.h.hit_row, S.d.hit_row, n * sizeof(int32_t), hipMemcpyDeviceToHost, S.stream));
     S.busy = true;

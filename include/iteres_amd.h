@@ -69,8 +69,8 @@ void itx_table_destroy(itx_table *t);
 typedef struct itx_table_info {
     uint64_t n_rows, n_rep, n_fam, n_cla;
     uint64_t cov_len;      /* sum of rep_len: length of the concatenated coverage vectors          */
-    uint64_t n_u64;        /* elements of the u64 accumulator block (see itx_engine_create)        */
-    uint64_t n_u32;        /* elements of the u32 accumulator block                                */
+    uint64_t n_units;      /* distinct (repName, repFamily, repClass) triples among the rows       */
+    uint64_t n_slots;      /* consensus slots the device accumulates over: sum over units of (rep_len + 1) */
     uint64_t table_bytes;  /* device bytes the table occupies                                      */
     int32_t  n_chrom, bin_shift, device, reserved;
 } itx_table_info;
@@ -118,12 +118,8 @@ typedef struct itx_batch {
 #define ITX_FLAG5(bamflag) ((uint8_t)((((bamflag) & 0x1) ? 1 : 0) | (((bamflag) & 0x4) ? 2 : 0) | (((bamflag) & 0x8) ? 4 : 0) | \
                                       (((bamflag) & 0x10) ? 8 : 0) | (((bamflag) & 0x40) ? 16 : 0)))
 
-/* batch_capacity = largest n a single submit may carry. u64_accum / u32_accum: optional
- * caller-owned DEVICE buffers of itx_table_info.n_u64 / n_u32 elements (zeroed by the caller) to
- * accumulate into — this is what a multi-GPU driver all-reduces (sum) across ranks before
- * itx_engine_finish; pass NULL to let the engine own them. */
-int itx_engine_create(const itx_table *t, const itx_params *p, size_t batch_capacity,
-                      void *u64_accum, void *u32_accum, itx_engine **out);
+/* batch_capacity = largest n a single submit may carry. */
+int itx_engine_create(const itx_table *t, const itx_params *p, size_t batch_capacity, itx_engine **out);
 void itx_engine_destroy(itx_engine *e);
 
 /* tid2chrom[tid] for the BAM header in use: index into chrom_size[], or -1 when the (possibly
@@ -146,14 +142,15 @@ int itx_engine_staging(itx_engine *e, int slot, itx_staging *out);
 int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has_paired, int want_hits);
 int itx_engine_wait_slot(itx_engine *e, int slot);
 
-/* Same work on a batch that is ALREADY in device memory (pointers in `b` are device pointers),
- * enqueued on `stream` (a hipStream_t, NULL = the null stream). d_hit_row: optional device
- * int32[n] for the chosen rows. Returns after enqueueing. */
+/* Same work on a batch that is ALREADY in device memory (pointers in `b` are device pointers, each
+ * 16-byte aligned), enqueued on `stream` (a hipStream_t, NULL = the null stream). d_hit_row: optional
+ * device int32[n] (16-byte aligned) for the chosen rows. Returns after enqueueing. Submissions of one
+ * engine must be stream-ordered with respect to each other. */
 int itx_engine_submit_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
 /* Classification only (no accumulation): cuskent/binRange.c:196-227 + generic.c:950-970 per record. */
 int itx_engine_classify_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
 int itx_engine_sync(itx_engine *e);
-/* Zero every accumulator (also caller-owned ones). */
+/* Zero every accumulator. */
 int itx_engine_reset(itx_engine *e);
 
 /* What the loop leaves behind for the writers (generic.c:53-113, 1709-1746). Any pointer may be
@@ -171,6 +168,18 @@ typedef struct itx_result {
  * them to the host pointers of `out`. The raw accumulators are left untouched, so more batches may
  * follow and finish may be called again. */
 int itx_engine_finish(itx_engine *e, const itx_result *out);
+
+/* Multi-GPU: every output is a commutative integer sum over records, so ranks process disjoint
+ * parts of the stream against replicated tables and exchange ONE compact partial at the end:
+ *   itx_engine_partial_size   -> element counts of the partial: n_u64 x uint64 and n_u32 x uint32
+ *   itx_engine_export_partial -> writes this engine's partial into caller-owned DEVICE buffers
+ *                                (what the driver all-reduces with RCCL, sum, over xGMI)
+ *   itx_engine_finish_partial -> like itx_engine_finish, but from (reduced) partial buffers
+ * The partial is [cnt[16] | per-unit read counts] as u64 and [coverage difference arrays] (stat) or
+ * [per-locus counts] (filter) as u32; sums are mod 2^64 / 2^32 like the reference's counters. */
+int itx_engine_partial_size(const itx_engine *e, uint64_t *n_u64, uint64_t *n_u32);
+int itx_engine_export_partial(itx_engine *e, void *d_u64, void *d_u32, void *stream);
+int itx_engine_finish_partial(itx_engine *e, const void *d_u64, const void *d_u32, const itx_result *out);
 
 /* Device time spent in the engine's kernels since the last reset, from HIP events recorded on the
  * submitting stream around each submit_device/submit_slot (milliseconds), and the number of

@@ -13,9 +13,9 @@ struct __attribute__((aligned(16))) ItxIv {
     int32_t  pmax_e;      // max e over this chromosome's intervals [first .. this]: scan-stop bound
     uint32_t cs;          // consensus_start as the reference parses it (generic.c:1596-1600)
     uint32_t jcap;        // min(consensus_end, repeat length): first consensus index NOT incremented
-    uint32_t covslot;     // first slot of the interval's repName inside the slot space (rep_len+1 slots per name)
-    uint32_t zslot;       // covslot + rep_len: the name's extra slot (never part of the coverage output)
-    uint32_t famcla;      // fam << 16 | cla
+    uint32_t covslot;     // first slot of the interval's unit inside the slot space (rep_len+1 slots per unit)
+    uint32_t zslot;       // covslot + rep_len: the unit's extra slot (never part of the coverage output)
+    uint32_t unit;        // the row's (repName, repFamily, repClass) unit
 };
 static_assert(sizeof(ItxIv) == 32, "ItxIv must be 32 bytes");
 
@@ -24,50 +24,65 @@ struct ItxDevTable {
     const ItxIv    *iv;         // [n_rows]
     const uint32_t *rank;       // [n_rows] position in binKeeperFind's list order within the chromosome
     const int32_t  *orig;       // [n_rows] sorted index -> caller's row index
-    const uint32_t *chrom_off;  // [n_chrom+1] interval range of each chromosome
-    const uint32_t *bin_off;    // [n_chrom+1] start of each chromosome's slice of bidx
-    const uint32_t *bidx;       // bidx[bin_off[c] + b] = chrom_off[c] + #{intervals of c with s < (b << shift)}
-    const int32_t  *chrom_size; // [n_chrom] (int, as binKeeperNew(0, size) holds it)
-    int32_t  n_chrom;
+    const uint2    *bl;         // binned index, one slice per chromosome (ItxTidRec.bin_base), per bin b of 2^shift bp:
+                                //   .x = first index with s >= (b << shift)          (upper bound of "s < x" queries)
+                                //   .y = first index with pmax_e > (b << shift)      (lower bound of what can still overlap)
     int32_t  shift;
     uint32_t n_rows;
-    uint32_t n_rep, n_fam, n_cla;
-    uint32_t n_slots;           // sum(rep_len + 1)
+    uint32_t n_units;
+    uint32_t n_slots;           // sum over units of (rep_len + 1)
 };
 
-// Layout of the accumulator blocks (element offsets).
-//   u64 block: cnt[16] | rep[2*n_rep] | fam[2*n_fam] | cla[2*n_cla]
-//   u32 block: A_all[n_slots] | A_uniq[n_slots] | B_all[n_slots] | B_uniq[n_slots] | locus[n_rows]
-// A = "range starts here" counts, B = "range ends here" counts in slot space; coverage of a name is the
-// prefix sum of A-B over its slots, its read count is sum(A) (every classified read contributes exactly
-// one start). All sums are mod 2^32 / 2^64 like the reference's unsigned counters.
+// Everything the kernels need to know about one BAM reference id, 32 bytes: one load per record
+// (wave-uniform for coordinate-sorted input) instead of a chain of per-chromosome lookups.
+struct __attribute__((aligned(16))) ItxTidRec {
+    int32_t  chrom;      // index into chrom_size[], -1 unknown / size 2 (generic.c:793-801), -2 dropped by -C (generic.c:783-784)
+    int32_t  size;       // chromosome size (int, as binKeeperNew(0, size) holds it)
+    uint32_t iv_lo, iv_hi;   // the chromosome's interval range in the table
+    uint32_t bin_base;   // start of the chromosome's slice of ItxDevTable.bl
+    uint32_t pad[3];
+};
+static_assert(sizeof(ItxTidRec) == 32, "ItxTidRec must be 32 bytes");
+
+// Raw device accumulators (element offsets).
+//   u64: cnt[16]
+//   u32: A_all[n_slots] | A_uniq[n_slots] | B_all[n_slots] | B_uniq[n_slots] | locus[n_rows]
+// A = "a read's consensus range starts here" counts, B = "ends here" counts, per slot. A unit's coverage
+// is the prefix sum of A-B over its slots and its read count is sum(A): every classified read records
+// exactly one start (in the unit's extra slot when it adds no coverage). Read counts of names, families
+// and classes are sums of unit counts. All sums are mod 2^32 / 2^64 like the reference's counters.
 struct ItxAccumLayout {
-    uint64_t cnt, rep, fam, cla, n_u64;
     uint64_t a_all, a_uniq, b_all, b_uniq, locus, n_u32;
 };
-static inline ItxAccumLayout itx_accum_layout(uint64_t n_rep, uint64_t n_fam, uint64_t n_cla, uint64_t n_slots, uint64_t n_rows)
+static inline ItxAccumLayout itx_accum_layout(uint64_t n_slots, uint64_t n_rows)
 {
     ItxAccumLayout L;
-    L.cnt = 0; L.rep = 16; L.fam = L.rep + 2 * n_rep; L.cla = L.fam + 2 * n_fam; L.n_u64 = L.cla + 2 * n_cla;
     L.a_all = 0; L.a_uniq = n_slots; L.b_all = 2 * n_slots; L.b_uniq = 3 * n_slots; L.locus = 4 * n_slots;
     L.n_u32 = L.locus + n_rows;
     return L;
 }
+// The partial a multi-GPU driver reduces (include/iteres_amd.h: itx_engine_export_partial):
+//   u64: cnt[16] | unit_all[n_units] | unit_uniq[n_units]
+//   u32: stat  : D_all[n_slots] | D_uniq[n_slots]   (D = A - B)
+//        filter: locus[n_rows]  (per SORTED row)
 
 struct itx_table {
     int device;
     int n_chrom, shift;
-    uint32_t n_rows, n_rep, n_fam, n_cla, n_slots;
+    uint32_t n_rows, n_rep, n_fam, n_cla, n_units, n_slots;
     uint64_t cov_len;
     uint64_t table_bytes;
     ItxDevTable dev;
-    // host copies used by finish()/info
+    // host copies used by finish()/info/set_tidmap
     uint32_t *h_rep_len;     // [n_rep]
-    uint32_t *h_covslot;     // [n_rep+1] first slot of each name
+    uint32_t *h_chrom_off;   // [n_chrom+1]
+    uint32_t *h_bin_off;     // [n_chrom+1]
+    int32_t  *h_chrom_size;  // [n_chrom]
     void *d_all;             // single device allocation backing every table array
-    uint32_t *d_rep_len;     // [n_rep]
-    uint32_t *d_covslot;     // [n_rep+1]
-    uint64_t *d_covoff;      // [n_rep+1] offsets into the concatenated coverage vectors
+    // per unit (device): slot range, ids, where its coverage lands, whether it is its name's only unit
+    uint32_t *d_unit_slot;   // [n_units+1]
+    uint4    *d_unit_ids;    // [n_units] (rep, fam, cla, solo)
+    uint64_t *d_unit_covoff; // [n_units] offset of the unit's repName inside the concatenated coverage vectors
 };
 
 void itx_set_error(const char *fmt, ...);
@@ -88,7 +103,7 @@ struct ItxRunParams {
     uint32_t isize_max;
     int32_t  treat, discard, mode;
     int32_t  n_tid;
-    const int32_t *tid2chrom;   // device
+    const ItxTidRec *tidrec;    // device, [n_tid]
 };
 
 struct ItxDevBatch {
@@ -97,9 +112,15 @@ struct ItxDevBatch {
     const int32_t *mpos, *isize;   // may be null
 };
 
-// kernels.hip launch wrappers -----------------------------------------------------------------
-struct ItxWork;   // scratch owned by the engine (partition path)
-int itx_launch_atomic(const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, int do_accum,
-                      int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, hipStream_t st);
-int itx_launch_finalize(const itx_table *t, const uint64_t *u64, const uint32_t *u32, const ItxAccumLayout &L,
-                        uint64_t *d_rep_out, uint32_t *d_cov, uint32_t *d_cov_uniq, hipStream_t st);
+// Streaming kernel (itx_stream.hip): one launch classifies n records and, per `what`, does nothing else,
+// accumulates with global atomics (stat: A/B arrays, filter: per-locus counts) or emits keys.
+enum { ITX_DO_CLASSIFY = 0, ITX_DO_ATOMIC_STAT = 1, ITX_DO_ATOMIC_LOCUS = 2, ITX_DO_EMIT = 3 };
+#define ITX_STREAM_TILE 1024u      // records per workgroup iteration (4 waves x 64 lanes x 4 records)
+int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, size_t span,
+                      unsigned n_blocks, int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, uint32_t *keys0,
+                      uint32_t *blk_cnt, hipStream_t st);
+// finish-time kernels (itx_finalize.hip)
+int itx_launch_export(const itx_table *t, int mode, const uint64_t *u64, const uint32_t *u32, const ItxAccumLayout &L, uint64_t *p64,
+                      uint32_t *p32, hipStream_t st);
+int itx_launch_finish(const itx_table *t, int mode, const uint64_t *p64, const uint32_t *p32, uint64_t *d_counts /*2*(rep+fam+cla)*/,
+                      uint32_t *d_cov, uint32_t *d_cov_uniq, uint32_t *d_locus_out, hipStream_t st);

@@ -1,4 +1,4 @@
-// itx_device.h — device functions shared by every kernel: per-record coordinate derivation
+// itx_device.h — device functions shared by the kernels: per-record coordinate derivation
 // (generic.c:748-905) and overlap classification (cuskent/binRange.c:196-227 + generic.c:950-970).
 #pragma once
 #include "itx_common.h"
@@ -10,36 +10,42 @@
 #define F5_REVERSE 8u
 #define F5_READ1 16u
 
+#define ITX_WIN 128          // intervals a wave stages in LDS for its tile of records (ItxIv each)
+
+// One record's raw fields as the host decoder hands them over.
+struct ItxRaw {
+    int32_t tid, pos, tmpend;
+    uint32_t mapq, fl;
+};
+
 // What one record contributes to cnt[] (generic.c:1048-1060), as a bit set, plus its interval.
-// bit k set => cnt[k] += 1.  (cnt[8] and cnt[12] are never touched on the device.)
+// bit k set => cnt[k] += 1.  (cnt[8] and cnt[12] are never touched on the device; cnt[11] == cnt[7].)
 struct ItxDerived {
     uint32_t cntbits;
     uint32_t start, end;   // the reference's unsigned start/end
-    int32_t  chrom;        // >= 0 when the record goes on to the lookup
+    bool     ok;           // the record goes on to the lookup
     bool     uniq;         // MAPQ >= -Q
 };
 
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-// generic.c:748-922 for one record. Returns with chrom < 0 when the record is dropped before the lookup.
-__device__ __forceinline__ ItxDerived itx_derive(const ItxRunParams &P, const ItxDevTable &T, const ItxDevBatch &B, size_t i)
+// generic.c:748-922 for one record. tr = first 16 bytes of the record's ItxTidRec (chrom, size, iv_lo, iv_hi),
+// chrom = -1 when the tid is outside the header. i indexes mpos/isize (only read for paired records).
+__device__ __forceinline__ ItxDerived itx_derive(const ItxRunParams &P, const ItxDevBatch &B, const ItxRaw &r, const uint4 &tr, size_t i)
 {
     ItxDerived d;
-    d.chrom = -1;
+    d.ok = false;
     d.start = d.end = 0;
-    const uint32_t fl = B.flag5[i];
-    const uint32_t qual = B.mapq[i];
-    d.uniq = qual >= P.mapq_min;
+    const uint32_t fl = r.fl;
+    d.uniq = r.mapq >= P.mapq_min;
     // generic.c:748-759: which "read end" counter
     const bool end1 = !(fl & F5_PAIRED) || (fl & F5_READ1) || P.treat;
     d.cntbits = end1 ? 1u : 2u;
     if (fl & F5_UNMAP) return d;                                  // generic.c:764
     d.cntbits |= end1 ? (1u << 2) : (1u << 3);                   // generic.c:768-779
-    const int32_t tid = B.tid[i];
     // generic.c:781-801; a tid outside the header crashes the reference, here it is "unknown chromosome"
-    const int32_t chrom = (tid >= 0 && tid < P.n_tid) ? P.tid2chrom[tid] : -1;
-    if (chrom < 0) return d;
-    const uint32_t cend = (uint32_t)(T.chrom_size[chrom] - 1);   // generic.c:796
+    if ((int32_t)tr.x < 0) return d;
+    const uint32_t cend = (uint32_t)((int32_t)tr.y - 1);         // generic.c:796
     if (cend == 1u) return d;                                    // generic.c:797
     d.cntbits |= end1 ? (1u << 4) : (1u << 5);                   // generic.c:802-813
     bool se_style;
@@ -49,7 +55,7 @@ __device__ __forceinline__ ItxDerived itx_derive(const ItxRunParams &P, const It
         if (!(fl & F5_MUNMAP)) {
             if (!(fl & F5_READ1)) return d;                      // generic.c:858-860
             const int32_t isz = B.isize[i];
-            const uint32_t a = (uint32_t)(isz < 0 ? -isz : isz);
+            const uint32_t a = isz < 0 ? 0u - (uint32_t)isz : (uint32_t)isz;
             if (a > P.isize_max || isz == 0) return d;           // generic.c:839-840
             se_style = false;
         } else {
@@ -60,11 +66,11 @@ __device__ __forceinline__ ItxDerived itx_derive(const ItxRunParams &P, const It
         se_style = true;
     }
     d.cntbits |= (1u << 6);                                       // reads_mapped
-    if (d.uniq) d.cntbits |= (1u << 7) | (1u << 11);             // reads_mapped_unique, reads_nonredundant_unique (no -R here)
+    if (d.uniq) d.cntbits |= (1u << 7);                           // reads_mapped_unique (== reads_nonredundant_unique without -R)
     uint32_t start, end;
     if (se_style) {                                               // generic.c:819-833
-        start = (uint32_t)B.pos[i];
-        end = umin32(cend, (uint32_t)B.tmpend[i]);
+        start = (uint32_t)r.pos;
+        end = umin32(cend, (uint32_t)r.tmpend);
         if (P.extension) {
             if (!(fl & F5_REVERSE)) {
                 end = umin32(start + P.extension, cend);
@@ -75,7 +81,7 @@ __device__ __forceinline__ ItxDerived itx_derive(const ItxRunParams &P, const It
     } else {                                                      // generic.c:845-855
         const int32_t isz = B.isize[i];
         if (isz > 0) {
-            start = (uint32_t)B.pos[i];
+            start = (uint32_t)r.pos;
             end = umin32(cend, start + (uint32_t)isz);
         } else {
             start = (uint32_t)B.mpos[i];
@@ -84,7 +90,7 @@ __device__ __forceinline__ ItxDerived itx_derive(const ItxRunParams &P, const It
     }
     d.start = start;
     d.end = end;
-    d.chrom = chrom;
+    d.ok = true;
     return d;
 }
 
@@ -98,69 +104,84 @@ __device__ __forceinline__ float itx_cov(uint32_t start, uint32_t end, int32_t s
     return den == 0.0f ? 0.0f : __fdiv_rn((float)ov, den);
 }
 
-// Returns the SORTED index of the row the reference would pick for [start,end) on `chrom`, or -1.
-// Candidates: rows with s < end' are [chrom_lo, hi); hi comes from the binned start index, then the
-// scan walks down while the prefix-max of the ends still exceeds start'. Hits are rows with positive
-// clipped overlap (binRange.c:216). With one hit it is the answer; with several, the reference's rule
-// "last hit, in list order, whose coverage exceeds the previous hit's" (generic.c:955-959) is replayed
-// through the precomputed list-order ranks.
-__device__ __forceinline__ int32_t itx_classify(const ItxDevTable &T, int32_t chrom, uint32_t ustart, uint32_t uend, float min_cov)
+__device__ __forceinline__ int32_t clip_ov(int32_t s, int32_t e, int32_t qs, int32_t qe)
 {
-    int32_t qs = (int32_t)ustart, qe = (int32_t)uend;              // binKeeperFind(bk, int start, int end)
-    const int32_t maxPos = T.chrom_size[chrom];
-    if (qs < 0) qs = 0;                                            // binRange.c:204-206
-    if (qe > maxPos) qe = maxPos;
-    if (qs >= qe) return -1;
-    const uint32_t lo = T.chrom_off[chrom];
-    if (lo == T.chrom_off[chrom + 1]) return -1;
-    const uint32_t *bi = T.bidx + T.bin_off[chrom] + ((uint32_t)qe >> T.shift);
-    uint32_t hi = bi[0];
-    uint32_t top = bi[1];
-    if (top - hi > 8) {                                            // crowded bin: binary search for first s >= qe
-        uint32_t a = hi, b = top;
-        while (a < b) {
-            uint32_t m = (a + b) >> 1;
-            if (T.iv[m].s < qe) a = m + 1; else b = m;
-        }
-        hi = a;
-    } else {
-        while (hi < top && T.iv[hi].s < qe) hi++;
+    return (e < qe ? e : qe) - (s > qs ? s : qs);                 // cuskent/common.c:2824-2831 on the clipped query
+}
+
+// Candidate accessors: the same algorithm runs over global memory (any input order) or over the
+// wave's LDS window (coordinate-sorted input, the fast path).
+struct IvGlobal {
+    const ItxIv *iv;
+    const uint32_t *rank;
+    __device__ __forceinline__ int32_t s(uint32_t k) const { return iv[k].s; }
+    __device__ __forceinline__ void sep(uint32_t k, int32_t &s_, int32_t &e_, int32_t &pm) const
+    {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&iv[k]);
+        s_ = (int32_t)v.x; e_ = (int32_t)v.y; pm = (int32_t)v.z;
     }
+    __device__ __forceinline__ uint32_t rk(uint32_t k) const { return rank[k]; }
+};
+struct IvLds {
+    const uint4 *w;            // entry j at w[2j], w[2j+1]
+    const uint32_t *rank;      // global ranks, indexed base + j
+    uint32_t base;
+    __device__ __forceinline__ int32_t s(uint32_t j) const { return (int32_t)w[2 * j].x; }
+    __device__ __forceinline__ void sep(uint32_t j, int32_t &s_, int32_t &e_, int32_t &pm) const
+    {
+        const uint4 v = w[2 * j];
+        s_ = (int32_t)v.x; e_ = (int32_t)v.y; pm = (int32_t)v.z;
+    }
+    __device__ __forceinline__ uint32_t rk(uint32_t j) const { return rank[base + j]; }
+};
+
+// Picks, among candidates [lo, hi) (hi = first candidate with s >= qe), the row the reference would
+// pick, or -1. Hits are rows with positive clipped overlap (binRange.c:216); the scan walks down while
+// the prefix-max of the ends still exceeds qs. One hit is the answer; with several, the reference's
+// rule "last hit, in list order, whose coverage exceeds the previous hit's" (generic.c:955-959) is
+// replayed through the precomputed list-order ranks.
+template <class ACC>
+__device__ __forceinline__ int32_t itx_pick(const ACC &A, uint32_t lo, uint32_t hi, int32_t qs, int32_t qe, uint32_t ustart, uint32_t uend,
+                                            float min_cov)
+{
     int32_t n = 0;
     uint32_t only = 0, low = hi;
+    int32_t os = 0, oe = 0;
     for (uint32_t k = hi; k > lo;) {
         --k;
-        const int32_t pm = T.iv[k].pmax_e;
+        int32_t s, e, pm;
+        A.sep(k, s, e, pm);
         if (pm <= qs) break;
         low = k;
-        const int32_t s = T.iv[k].s, e = T.iv[k].e;
-        const int32_t ov = (e < qe ? e : qe) - (s > qs ? s : qs);
-        if (ov > 0) {
+        if (clip_ov(s, e, qs, qe) > 0) {
             n++;
             only = k;
+            os = s;
+            oe = e;
         }
     }
     if (n == 0) return -1;
     uint32_t chosen = only;
     float tcov;
     if (n == 1) {
-        tcov = itx_cov(ustart, uend, T.iv[only].s, T.iv[only].e);
+        tcov = itx_cov(ustart, uend, os, oe);
     } else {
-        // several hits: for each hit find its predecessor in list order among the hits
         int64_t best_rank = -1;
         tcov = 0.0f;
         for (uint32_t i = low; i < hi; i++) {
-            const int32_t s = T.iv[i].s, e = T.iv[i].e;
-            if (((e < qe ? e : qe) - (s > qs ? s : qs)) <= 0) continue;
-            const uint32_t ri = T.rank[i];
+            int32_t s, e, pm;
+            A.sep(i, s, e, pm);
+            if (clip_ov(s, e, qs, qe) <= 0) continue;
+            const uint32_t ri = A.rk(i);
             const float ci = itx_cov(ustart, uend, s, e);
             int64_t pr = -1;
             float pc = 0.0f;
             for (uint32_t k = low; k < hi; k++) {
                 if (k == i) continue;
-                const int32_t s2 = T.iv[k].s, e2 = T.iv[k].e;
-                if (((e2 < qe ? e2 : qe) - (s2 > qs ? s2 : qs)) <= 0) continue;
-                const uint32_t rk = T.rank[k];
+                int32_t s2, e2, pm2;
+                A.sep(k, s2, e2, pm2);
+                if (clip_ov(s2, e2, qs, qe) <= 0) continue;
+                const uint32_t rk = A.rk(k);
                 if (rk < ri && (int64_t)rk > pr) {
                     pr = rk;
                     pc = itx_cov(ustart, uend, s2, e2);
@@ -176,6 +197,46 @@ __device__ __forceinline__ int32_t itx_classify(const ItxDevTable &T, int32_t ch
     }
     if (tcov < min_cov) return -1;                                 // generic.c:961-962
     return (int32_t)chosen;
+}
+
+// Generic per-lane lookup straight from global memory (any record order). qs/qe already clipped.
+__device__ __forceinline__ int32_t itx_classify_lane(const ItxDevTable &T, uint32_t iv_lo, uint32_t bin_base, int32_t qs, int32_t qe,
+                                                     uint32_t ustart, uint32_t uend, float min_cov)
+{
+    const uint2 *bl = T.bl + bin_base + ((uint32_t)qe >> T.shift);
+    uint32_t hi = bl[0].x;
+    const uint32_t top = bl[1].x;
+    if (top - hi > 8) {                                            // crowded bin: binary search for first s >= qe
+        uint32_t a = hi, b = top;
+        while (a < b) {
+            const uint32_t m = (a + b) >> 1;
+            if (T.iv[m].s < qe) a = m + 1; else b = m;
+        }
+        hi = a;
+    } else {
+        while (hi < top && T.iv[hi].s < qe) hi++;
+    }
+    IvGlobal A{T.iv, T.rank};
+    return itx_pick(A, iv_lo, hi, qs, qe, ustart, uend, min_cov);
+}
+
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t t = __shfl_xor(v, o, 64);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t t = __shfl_xor(v, o, 64);
+        v = t > v ? t : v;
+    }
+    return v;
 }
 
 // Consensus range a classified read increments (generic.c:991-1007) in slot space:

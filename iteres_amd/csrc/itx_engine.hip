@@ -1,5 +1,6 @@
 // itx_engine.hip — the C ABI of include/iteres_amd.h: engine life cycle, pinned double buffering,
-// submission, finish. No CPU fallback anywhere: without a usable HIP device every entry point fails.
+// submission, partial export (multi-GPU), finish. No CPU fallback anywhere: without a usable HIP device
+// every entry point fails.
 #include "itx_common.h"
 #include "itx_partition.h"
 
@@ -22,22 +23,24 @@ struct itx_engine {
     itx_params p;
     size_t cap;
     ItxAccumLayout L;
-    uint64_t *u64;
-    uint32_t *u32;
-    bool own_u64, own_u32;
-    int32_t *d_tidmap;
+    uint64_t *u64;        // cnt[16]
+    uint32_t *u32;        // raw A/B slot arrays + per-locus counts
+    ItxTidRec *d_tidrec;
     int n_tid, cap_tid;
     ItxSlot slot[2];
     hipStream_t compute;  // every kernel of the slot path runs here, in submission order: batches never overlap
                           // each other (the partition path's scratch and the exclusive window updates rely on it)
     bool slots_ready;
-    // finalize outputs (device), allocated on first finish
-    uint64_t *d_rep_out;
+    // finish-time buffers (device), allocated on first use
+    uint64_t *p64;        // own partial
+    uint32_t *p32;
+    uint64_t *d_counts;
     uint32_t *d_cov, *d_cov_uniq, *d_locus_out;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     double kernel_ms;
     uint64_t records;
     ItxPartWork *pw;      // scratch of the partition path
+    unsigned max_blocks;
 };
 
 static int use_device(const itx_engine *e)
@@ -46,19 +49,28 @@ static int use_device(const itx_engine *e)
     return ITX_OK;
 }
 
-extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t batch_capacity, void *u64_accum,
-                                 void *u32_accum, itx_engine **out)
+static size_t partial_u64(const itx_engine *e) { return 16 + 2 * (size_t)e->t->n_units; }
+static size_t partial_u32(const itx_engine *e)
+{
+    return e->p.mode == ITX_MODE_STAT ? 2 * (size_t)e->t->n_slots : (size_t)e->t->n_rows;
+}
+
+extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t batch_capacity, itx_engine **out)
 {
     if (!t || !p || !out || batch_capacity == 0) {
         itx_set_error("itx_engine_create: bad argument");
         return ITX_E_ARG;
     }
-    if (batch_capacity >= (1ull << 31)) {
-        itx_set_error("itx_engine_create: batch_capacity %zu >= 2^31", batch_capacity);
+    if (batch_capacity >= (1ull << 31) - 2 * ITX_STREAM_TILE) {
+        itx_set_error("itx_engine_create: batch_capacity %zu too large (< 2^31)", batch_capacity);
         return ITX_E_LIMIT;
     }
     if (p->mode != ITX_MODE_STAT && p->mode != ITX_MODE_FILTER) {
         itx_set_error("itx_engine_create: unknown mode %d", p->mode);
+        return ITX_E_ARG;
+    }
+    if (p->accum != ITX_ACCUM_DEFAULT && p->accum != ITX_ACCUM_ATOMIC && p->accum != ITX_ACCUM_PARTITION) {
+        itx_set_error("itx_engine_create: unknown accumulate path %d", p->accum);
         return ITX_E_ARG;
     }
     ITX_HIP(hipSetDevice(t->device));
@@ -67,36 +79,36 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     e->t = t;
     e->p = *p;
     if (e->p.accum == ITX_ACCUM_DEFAULT) e->p.accum = ITX_ACCUM_PARTITION;
-    if (e->p.mode == ITX_MODE_FILTER) e->p.accum = ITX_ACCUM_ATOMIC;   // per-locus counts: one aggregated atomic per run
+    if (e->p.mode == ITX_MODE_FILTER) e->p.accum = ITX_ACCUM_ATOMIC;   // per-locus counts: one atomic per run of equal rows
     e->cap = batch_capacity;
-    e->L = itx_accum_layout(t->n_rep, t->n_fam, t->n_cla, t->n_slots, t->n_rows);
-    e->u64 = (uint64_t *)u64_accum;
-    e->u32 = (uint32_t *)u32_accum;
-    e->own_u64 = e->own_u32 = false;
-    e->d_tidmap = nullptr;
+    e->L = itx_accum_layout(t->n_slots, t->n_rows);
+    e->u64 = nullptr;
+    e->u32 = nullptr;
+    e->d_tidrec = nullptr;
     e->n_tid = e->cap_tid = 0;
     e->slots_ready = false;
     e->compute = nullptr;
     memset(e->slot, 0, sizeof e->slot);
-    e->d_rep_out = nullptr;
+    e->p64 = nullptr;
+    e->p32 = nullptr;
+    e->d_counts = nullptr;
     e->d_cov = e->d_cov_uniq = e->d_locus_out = nullptr;
     e->kernel_ms = 0;
     e->records = 0;
     e->pw = nullptr;
-    hipError_t he;
-    if (!e->u64) {
-        he = hipMalloc((void **)&e->u64, e->L.n_u64 * sizeof(uint64_t));
-        if (he != hipSuccess) goto nomem;
-        e->own_u64 = true;
-        he = hipMemset(e->u64, 0, e->L.n_u64 * sizeof(uint64_t));
-        if (he != hipSuccess) goto nomem;
+    e->max_blocks = 2048;
+    if (const char *s = getenv("ITX_STREAM_BLOCKS")) {
+        const long v = atol(s);
+        if (v >= 1 && v <= 2048) e->max_blocks = (unsigned)v;
     }
-    if (!e->u32) {
-        he = hipMalloc((void **)&e->u32, e->L.n_u32 * sizeof(uint32_t));
-        if (he != hipSuccess) goto nomem;
-        e->own_u32 = true;
-        he = hipMemset(e->u32, 0, e->L.n_u32 * sizeof(uint32_t));
-        if (he != hipSuccess) goto nomem;
+    hipError_t he = hipMalloc((void **)&e->u64, 16 * sizeof(uint64_t));
+    if (he == hipSuccess) he = hipMemset(e->u64, 0, 16 * sizeof(uint64_t));
+    if (he == hipSuccess) he = hipMalloc((void **)&e->u32, (e->L.n_u32 + 4) * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(e->u32, 0, (e->L.n_u32 + 4) * sizeof(uint32_t));
+    if (he != hipSuccess) {
+        itx_set_error("itx_engine_create: device allocation failed: %s", hipGetErrorString(he));
+        itx_engine_destroy(e);
+        return ITX_E_NOMEM;
     }
     if (e->p.accum == ITX_ACCUM_PARTITION) {
         int rc = itx_part_create(t, batch_capacity, &e->pw);
@@ -107,10 +119,6 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     }
     *out = e;
     return ITX_OK;
-nomem:
-    itx_set_error("itx_engine_create: device allocation failed: %s", hipGetErrorString(he));
-    itx_engine_destroy(e);
-    return ITX_E_NOMEM;
 }
 
 static void free_staging(itx_staging *h, itx_staging *d)
@@ -140,13 +148,9 @@ extern "C" void itx_engine_destroy(itx_engine *e)
             if (e->slot[s].done) (void)hipEventDestroy(e->slot[s].done);
         }
     if (e->slots_ready && e->compute) (void)hipStreamDestroy(e->compute);
-    if (e->own_u64 && e->u64) (void)hipFree(e->u64);
-    if (e->own_u32 && e->u32) (void)hipFree(e->u32);
-    if (e->d_tidmap) (void)hipFree(e->d_tidmap);
-    if (e->d_rep_out) (void)hipFree(e->d_rep_out);
-    if (e->d_cov) (void)hipFree(e->d_cov);
-    if (e->d_cov_uniq) (void)hipFree(e->d_cov_uniq);
-    if (e->d_locus_out) (void)hipFree(e->d_locus_out);
+    void *bufs[] = {e->u64, e->u32, e->d_tidrec, e->p64, e->p32, e->d_counts, e->d_cov, e->d_cov_uniq, e->d_locus_out};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
     if (e->pw) itx_part_destroy(e->pw);
     delete e;
 }
@@ -166,12 +170,28 @@ extern "C" int itx_engine_set_tidmap(itx_engine *e, const int32_t *tid2chrom, in
     if (rc) return rc;
     ITX_HIP(hipDeviceSynchronize());   // earlier batches may still read the previous map
     if (n_tid > e->cap_tid) {
-        if (e->d_tidmap) ITX_HIP(hipFree(e->d_tidmap));
-        e->d_tidmap = nullptr;
-        ITX_HIP(hipMalloc((void **)&e->d_tidmap, sizeof(int32_t) * (size_t)(n_tid + 1)));
+        if (e->d_tidrec) ITX_HIP(hipFree(e->d_tidrec));
+        e->d_tidrec = nullptr;
+        ITX_HIP(hipMalloc((void **)&e->d_tidrec, sizeof(ItxTidRec) * (size_t)(n_tid + 1)));
         e->cap_tid = n_tid;
     }
-    if (n_tid) ITX_HIP(hipMemcpy(e->d_tidmap, tid2chrom, sizeof(int32_t) * (size_t)n_tid, hipMemcpyHostToDevice));
+    // one 32-byte record per BAM reference id: chromosome, its size, its slice of the table and of the binned index
+    std::vector<ItxTidRec> rec((size_t)n_tid);
+    const itx_table *t = e->t;
+    for (int i = 0; i < n_tid; i++) {
+        ItxTidRec &r = rec[i];
+        memset(&r, 0, sizeof r);
+        const int c = tid2chrom[i];
+        r.chrom = c < 0 ? (c == -2 ? -2 : -1) : c;
+        if (c >= 0) {
+            r.size = t->h_chrom_size[c];
+            r.iv_lo = t->h_chrom_off[c];
+            r.iv_hi = t->h_chrom_off[c + 1];
+            r.bin_base = t->h_bin_off[c];
+            if (r.size == 2) r.chrom = -1;             // generic.c:796-797: a size of exactly 2 reads as "not in the size file"
+        }
+    }
+    if (n_tid) ITX_HIP(hipMemcpy(e->d_tidrec, rec.data(), sizeof(ItxTidRec) * (size_t)n_tid, hipMemcpyHostToDevice));
     e->n_tid = n_tid;
     return ITX_OK;
 }
@@ -179,7 +199,7 @@ extern "C" int itx_engine_set_tidmap(itx_engine *e, const int32_t *tid2chrom, in
 static int ensure_slots(itx_engine *e)
 {
     if (e->slots_ready) return ITX_OK;
-    const size_t n = e->cap;
+    const size_t n = e->cap + ITX_STREAM_TILE;
     ITX_HIP(hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking));
     for (int s = 0; s < 2; s++) {
         ItxSlot &S = e->slot[s];
@@ -198,7 +218,7 @@ static int ensure_slots(itx_engine *e)
         BOTH(isize, int32_t)
         BOTH(hit_row, int32_t)
 #undef BOTH
-        S.h.capacity = S.d.capacity = n;
+        S.h.capacity = S.d.capacity = e->cap;
         S.busy = false;
     }
     e->slots_ready = true;
@@ -239,21 +259,24 @@ static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_h
     P.discard = e->p.discard_half_mapped;
     P.mode = e->p.mode;
     P.n_tid = e->n_tid;
-    P.tid2chrom = e->d_tidmap;
+    P.tidrec = e->d_tidrec;
     hipEvent_t a, b;
     ITX_HIP(hipEventCreate(&a));
     ITX_HIP(hipEventCreate(&b));
     ITX_HIP(hipEventRecord(a, st));
     int rc;
-    if (!accumulate)
-        rc = itx_launch_atomic(e->t->dev, P, B, n, 0, d_hit_row, e->u64, e->u32, e->L, st);
-    else if (e->p.accum == ITX_ACCUM_PARTITION)
+    if (accumulate && e->p.accum == ITX_ACCUM_PARTITION) {
         rc = itx_part_run(e->pw, e->t->dev, P, B, n, d_hit_row, e->u64, e->u32, e->L, st);
-    else
-        rc = itx_launch_atomic(e->t->dev, P, B, n, 1, d_hit_row, e->u64, e->u32, e->L, st);
+    } else {
+        size_t span = (n + e->max_blocks - 1) / e->max_blocks;
+        span = (span + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
+        const unsigned nb = (unsigned)((n + span - 1) / span);
+        const int what = !accumulate ? ITX_DO_CLASSIFY : (e->p.mode == ITX_MODE_STAT ? ITX_DO_ATOMIC_STAT : ITX_DO_ATOMIC_LOCUS);
+        rc = itx_launch_stream(what, e->t->dev, P, B, n, span, nb, d_hit_row, e->u64, e->u32, e->L, nullptr, nullptr, st);
+    }
     ITX_HIP(hipEventRecord(b, st));
     e->ev.emplace_back(a, b);
-    e->records += n;
+    if (accumulate) e->records += n;
     return rc;
 }
 
@@ -337,11 +360,7 @@ extern "C" int itx_engine_classify_device(itx_engine *e, const itx_batch *b, siz
     }
     int rc = use_device(e);
     if (rc) return rc;
-    uint64_t rec0 = e->records;
-    rc = run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, false);
-    e->records = rec0;
-    if (rc) return rc;
-    return ITX_OK;
+    return run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, false);
 }
 
 extern "C" int itx_engine_sync(itx_engine *e)
@@ -371,7 +390,7 @@ extern "C" int itx_engine_reset(itx_engine *e)
     if (!e) return ITX_E_ARG;
     int rc = itx_engine_sync(e);
     if (rc) return rc;
-    ITX_HIP(hipMemset(e->u64, 0, e->L.n_u64 * sizeof(uint64_t)));
+    ITX_HIP(hipMemset(e->u64, 0, 16 * sizeof(uint64_t)));
     ITX_HIP(hipMemset(e->u32, 0, e->L.n_u32 * sizeof(uint32_t)));
     fold_events(e);
     e->kernel_ms = 0;
@@ -379,12 +398,77 @@ extern "C" int itx_engine_reset(itx_engine *e)
     return ITX_OK;
 }
 
-// locus counts are accumulated per SORTED row; the caller wants its own row order.
-__global__ void k_permute_locus(const uint32_t *__restrict__ in, const int32_t *__restrict__ orig, uint32_t n,
-                                uint32_t *__restrict__ out)
+extern "C" int itx_engine_partial_size(const itx_engine *e, uint64_t *n_u64, uint64_t *n_u32)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[orig[i]] = in[i];
+    if (!e) {
+        itx_set_error("itx_engine_partial_size: bad argument");
+        return ITX_E_ARG;
+    }
+    if (n_u64) *n_u64 = partial_u64(e);
+    if (n_u32) *n_u32 = partial_u32(e);
+    return ITX_OK;
+}
+
+extern "C" int itx_engine_export_partial(itx_engine *e, void *d_u64, void *d_u32, void *stream)
+{
+    if (!e || !d_u64 || (!d_u32 && partial_u32(e))) {
+        itx_set_error("itx_engine_export_partial: bad argument");
+        return ITX_E_ARG;
+    }
+    int rc = use_device(e);
+    if (rc) return rc;
+    return itx_launch_export(e->t, e->p.mode, e->u64, e->u32, e->L, (uint64_t *)d_u64, (uint32_t *)d_u32, (hipStream_t)stream);
+}
+
+static int ensure_finish_buffers(itx_engine *e)
+{
+    const itx_table *t = e->t;
+    if (e->d_counts) return ITX_OK;
+    ITX_HIP(hipMalloc((void **)&e->d_counts, sizeof(uint64_t) * (2 * ((size_t)t->n_rep + t->n_fam + t->n_cla) + 2)));
+    ITX_HIP(hipMalloc((void **)&e->d_cov, sizeof(uint32_t) * (t->cov_len + 2)));
+    ITX_HIP(hipMalloc((void **)&e->d_cov_uniq, sizeof(uint32_t) * (t->cov_len + 2)));
+    ITX_HIP(hipMalloc((void **)&e->d_locus_out, sizeof(uint32_t) * ((size_t)t->n_rows + 2)));
+    return ITX_OK;
+}
+
+extern "C" int itx_engine_finish_partial(itx_engine *e, const void *d_u64, const void *d_u32, const itx_result *out)
+{
+    if (!e || !out || !d_u64 || (!d_u32 && partial_u32(e))) {
+        itx_set_error("itx_engine_finish_partial: bad argument");
+        return ITX_E_ARG;
+    }
+    int rc = use_device(e);
+    if (rc) return rc;
+    ITX_HIP(hipDeviceSynchronize());
+    rc = ensure_finish_buffers(e);
+    if (rc) return rc;
+    const itx_table *t = e->t;
+    rc = itx_launch_finish(t, e->p.mode, (const uint64_t *)d_u64, (const uint32_t *)d_u32, e->d_counts, e->d_cov, e->d_cov_uniq,
+                           e->d_locus_out, 0);
+    if (rc) return rc;
+    ITX_HIP(hipDeviceSynchronize());
+    if (out->cnt) {
+        uint64_t c[16];
+        ITX_HIP(hipMemcpy(c, d_u64, sizeof c, hipMemcpyDeviceToHost));
+        memcpy(out->cnt, c, 13 * sizeof(uint64_t));
+    }
+    const size_t R = t->n_rep, F = t->n_fam, Cn = t->n_cla;
+    if (out->rep_cnt && R) ITX_HIP(hipMemcpy(out->rep_cnt, e->d_counts, sizeof(uint64_t) * 2 * R, hipMemcpyDeviceToHost));
+    if (out->fam_cnt && F) ITX_HIP(hipMemcpy(out->fam_cnt, e->d_counts + 2 * R, sizeof(uint64_t) * 2 * F, hipMemcpyDeviceToHost));
+    if (out->cla_cnt && Cn)
+        ITX_HIP(hipMemcpy(out->cla_cnt, e->d_counts + 2 * R + 2 * F, sizeof(uint64_t) * 2 * Cn, hipMemcpyDeviceToHost));
+    if (e->p.mode == ITX_MODE_STAT) {
+        if (out->cov && t->cov_len) ITX_HIP(hipMemcpy(out->cov, e->d_cov, sizeof(uint32_t) * t->cov_len, hipMemcpyDeviceToHost));
+        if (out->cov_uniq && t->cov_len)
+            ITX_HIP(hipMemcpy(out->cov_uniq, e->d_cov_uniq, sizeof(uint32_t) * t->cov_len, hipMemcpyDeviceToHost));
+        if (out->locus_cnt && t->n_rows) memset(out->locus_cnt, 0, sizeof(uint32_t) * (size_t)t->n_rows);
+    } else {
+        if (out->locus_cnt && t->n_rows)
+            ITX_HIP(hipMemcpy(out->locus_cnt, e->d_locus_out, sizeof(uint32_t) * (size_t)t->n_rows, hipMemcpyDeviceToHost));
+        if (out->cov && t->cov_len) memset(out->cov, 0, sizeof(uint32_t) * t->cov_len);
+        if (out->cov_uniq && t->cov_len) memset(out->cov_uniq, 0, sizeof(uint32_t) * t->cov_len);
+    }
+    return ITX_OK;
 }
 
 extern "C" int itx_engine_finish(itx_engine *e, const itx_result *out)
@@ -395,47 +479,13 @@ extern "C" int itx_engine_finish(itx_engine *e, const itx_result *out)
     }
     int rc = itx_engine_sync(e);
     if (rc) return rc;
-    const itx_table *t = e->t;
-    if (!e->d_rep_out) {
-        ITX_HIP(hipMalloc((void **)&e->d_rep_out, sizeof(uint64_t) * (2 * (size_t)t->n_rep + 1)));
-        ITX_HIP(hipMalloc((void **)&e->d_cov, sizeof(uint32_t) * (t->cov_len + 1)));
-        ITX_HIP(hipMalloc((void **)&e->d_cov_uniq, sizeof(uint32_t) * (t->cov_len + 1)));
-        ITX_HIP(hipMalloc((void **)&e->d_locus_out, sizeof(uint32_t) * ((size_t)t->n_rows + 1)));
+    if (!e->p64) {
+        ITX_HIP(hipMalloc((void **)&e->p64, sizeof(uint64_t) * (partial_u64(e) + 2)));
+        ITX_HIP(hipMalloc((void **)&e->p32, sizeof(uint32_t) * (partial_u32(e) + 4)));
     }
-    if (out->cnt) {
-        uint64_t c[16];
-        ITX_HIP(hipMemcpy(c, e->u64 + e->L.cnt, sizeof c, hipMemcpyDeviceToHost));
-        memcpy(out->cnt, c, 13 * sizeof(uint64_t));
-    }
-    if (e->p.mode == ITX_MODE_STAT) {
-        rc = itx_launch_finalize(t, e->u64, e->u32, e->L, e->d_rep_out, e->d_cov, e->d_cov_uniq, 0);
-        if (rc) return rc;
-        ITX_HIP(hipDeviceSynchronize());
-        if (out->rep_cnt && t->n_rep)
-            ITX_HIP(hipMemcpy(out->rep_cnt, e->d_rep_out, sizeof(uint64_t) * 2 * (size_t)t->n_rep, hipMemcpyDeviceToHost));
-        if (out->fam_cnt && t->n_fam)
-            ITX_HIP(hipMemcpy(out->fam_cnt, e->u64 + e->L.fam, sizeof(uint64_t) * 2 * (size_t)t->n_fam, hipMemcpyDeviceToHost));
-        if (out->cla_cnt && t->n_cla)
-            ITX_HIP(hipMemcpy(out->cla_cnt, e->u64 + e->L.cla, sizeof(uint64_t) * 2 * (size_t)t->n_cla, hipMemcpyDeviceToHost));
-        if (out->cov && t->cov_len) ITX_HIP(hipMemcpy(out->cov, e->d_cov, sizeof(uint32_t) * t->cov_len, hipMemcpyDeviceToHost));
-        if (out->cov_uniq && t->cov_len)
-            ITX_HIP(hipMemcpy(out->cov_uniq, e->d_cov_uniq, sizeof(uint32_t) * t->cov_len, hipMemcpyDeviceToHost));
-        if (out->locus_cnt && t->n_rows) memset(out->locus_cnt, 0, sizeof(uint32_t) * (size_t)t->n_rows);
-    } else {
-        if (out->locus_cnt && t->n_rows) {
-            hipLaunchKernelGGL(k_permute_locus, dim3((t->n_rows + 255) / 256), dim3(256), 0, 0, e->u32 + e->L.locus, t->dev.orig,
-                               t->n_rows, e->d_locus_out);
-            ITX_HIP(hipGetLastError());
-            ITX_HIP(hipDeviceSynchronize());
-            ITX_HIP(hipMemcpy(out->locus_cnt, e->d_locus_out, sizeof(uint32_t) * (size_t)t->n_rows, hipMemcpyDeviceToHost));
-        }
-        if (out->rep_cnt && t->n_rep) memset(out->rep_cnt, 0, sizeof(uint64_t) * 2 * (size_t)t->n_rep);
-        if (out->fam_cnt && t->n_fam) memset(out->fam_cnt, 0, sizeof(uint64_t) * 2 * (size_t)t->n_fam);
-        if (out->cla_cnt && t->n_cla) memset(out->cla_cnt, 0, sizeof(uint64_t) * 2 * (size_t)t->n_cla);
-        if (out->cov && t->cov_len) memset(out->cov, 0, sizeof(uint32_t) * t->cov_len);
-        if (out->cov_uniq && t->cov_len) memset(out->cov_uniq, 0, sizeof(uint32_t) * t->cov_len);
-    }
-    return ITX_OK;
+    rc = itx_launch_export(e->t, e->p.mode, e->u64, e->u32, e->L, e->p64, e->p32, 0);
+    if (rc) return rc;
+    return itx_engine_finish_partial(e, e->p64, e->p32, out);
 }
 
 extern "C" int itx_engine_get_stats(itx_engine *e, itx_stats *out)
@@ -448,7 +498,7 @@ extern "C" int itx_engine_get_stats(itx_engine *e, itx_stats *out)
     out->kernel_ms = e->kernel_ms;
     out->records = e->records;
     uint64_t c[16];
-    ITX_HIP(hipMemcpy(c, e->u64 + e->L.cnt, sizeof c, hipMemcpyDeviceToHost));
+    ITX_HIP(hipMemcpy(c, e->u64, sizeof c, hipMemcpyDeviceToHost));
     out->hits = c[9];
     return ITX_OK;
 }

@@ -1,16 +1,16 @@
 // itx_partition.hip — ITX_ACCUM_PARTITION: accumulate without scattered global atomics.
 //
 // Problem: every classified read adds +1 at two consensus slots (range start / range end) of its
-// repName. Reads arrive in GENOME order, the slots are in REPEAT-NAME order: a transposition. Done
-// with global atomics it costs one memory-side atomic request per key (measured ~9 G/s on MI355X:
-// 10x the rest of the path). Here the transposition is done the radix way:
+// unit. Reads arrive in GENOME order, the slots are in REPEAT-NAME order: a transposition. Done with
+// global atomics it costs one memory-side atomic request per key (measured ~9 G/s on MI355X: 10x the
+// rest of the path). Here the transposition is done the radix way:
 //
-//   A  k_emit      one record per lane: derive -> classify -> 1-2 keys (slot<<2 | isEnd<<1 | uniq),
-//                  written compacted into the workgroup's own region (LDS cursor, no global atomic);
-//                  per-partition key counts, cnt[], family/class counts privatised in LDS.
-//   S  k_plan      one workgroup: exclusive scan of the partition counts, scatter cursors, and the
-//                  work list of (partition, key range) items for H (a partition with more than
-//                  ITX_CHUNK keys is split into several items).
+//   A  k_stream<EMIT> (itx_stream.hip)  1-2 keys per classified record (slot<<2 | isEnd<<1 | uniq),
+//                  written compacted into the workgroup's own region (LDS cursor, no global atomic).
+//   C  k_count     per-partition key counts: run lengths per wave (sorted input gives long runs), LDS
+//                  histogram per workgroup, one global add per touched partition.
+//   S  k_plan      one workgroup: exclusive scan of the counts, scatter cursors, and the work list of
+//                  (partition, key range) items for H (a partition with more than ITX_CHUNK keys is split).
 //   P  k_scatter   per 4096-key tile: LDS histogram with returning adds (= local ranks), one global
 //                  reservation per touched partition, keys written to their partition's range.
 //   H  k_hist      per item: LDS window of the partition's W slots (A|B counts, all:16|uniq:16 packed),
@@ -20,7 +20,6 @@
 //
 // Integer sums only: the result is independent of order, identical to the atomic path and the oracle.
 #include "itx_partition.h"
-#include "itx_device.h"
 
 #define PB 256              // threads per workgroup
 #define ITX_LOGW 13         // slots per partition (W = 8192): LDS window of k_hist = W * 8 bytes = 64 KiB
@@ -32,10 +31,10 @@
 struct ItxPartWork {
     size_t cap;            // records per batch
     uint32_t n_part;       // partitions
-    uint32_t n_blocks;     // workgroups of k_emit (fixed: regions are per workgroup)
+    uint32_t max_blocks;   // workgroups of the emit launch (regions are per workgroup)
     uint32_t max_items;
     uint32_t *keys0, *keys1;   // [2*cap]
-    uint32_t *blk_cnt;         // [n_blocks] keys emitted by each workgroup
+    uint32_t *blk_cnt;         // [max_blocks] keys emitted by each workgroup
     uint32_t *pcount;          // [n_part]
     uint32_t *pbase;           // [n_part+1]
     uint32_t *cursor;          // [n_part]
@@ -57,14 +56,13 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
     ItxPartWork *w = new ItxPartWork();
     w->cap = cap;
     w->n_part = n_part ? n_part : 1;
-    size_t nb = (cap + PB - 1) / PB;
-    if (nb > 2048) nb = 2048;
-    w->n_blocks = (uint32_t)nb;
+    w->max_blocks = 2048;
     w->max_items = w->n_part + (uint32_t)((2 * cap) / ITX_CHUNK) + 2;
+    const size_t kcap = 2 * (cap + ITX_STREAM_TILE) * 4 + 64;
     size_t off = 0;
-    const size_t o_k0 = off; off = al256(off + 2 * cap * 4 + 16);
-    const size_t o_k1 = off; off = al256(off + 2 * cap * 4 + 16);
-    const size_t o_bc = off; off = al256(off + (size_t)w->n_blocks * 4);
+    const size_t o_k0 = off; off = al256(off + kcap);
+    const size_t o_k1 = off; off = al256(off + kcap);
+    const size_t o_bc = off; off = al256(off + (size_t)w->max_blocks * 4);
     const size_t o_pc = off; off = al256(off + (size_t)w->n_part * 4);
     const size_t o_pb = off; off = al256(off + ((size_t)w->n_part + 1) * 4);
     const size_t o_cu = off; off = al256(off + (size_t)w->n_part * 4);
@@ -97,105 +95,32 @@ void itx_part_destroy(ItxPartWork *w)
     delete w;
 }
 
-// ------------------------------------------------------------------------------------------------ A
-__device__ __forceinline__ void lds_count_partition(uint32_t *s_pc, uint32_t part, bool has)
+// ------------------------------------------------------------------------------------------------ C
+__global__ __launch_bounds__(PB) void k_count(const uint32_t *__restrict__ keys0, const uint32_t *__restrict__ blk_cnt, size_t span,
+                                              uint32_t *__restrict__ pcount, uint32_t n_part)
 {
-    // lanes of a wave mostly share a partition (coordinate-sorted input): one LDS add per distinct value
-    unsigned long long mask = __ballot(has);
-    int guard = 0;
-    while (mask) {
-        if (++guard > 4) {                               // unsorted input: the rest go one by one
-            if (has && ((mask >> (threadIdx.x & 63)) & 1ull)) atomicAdd(&s_pc[part], 1u);
-            break;
-        }
-        const int leader = __ffsll((long long)mask) - 1;
-        const uint32_t p0 = __shfl(part, leader, 64);
-        const unsigned long long same = __ballot(has && part == p0) & mask;
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&s_pc[p0], (uint32_t)__popcll(same));
-        mask &= ~same;
-    }
-}
-
-__global__ __launch_bounds__(PB) void k_emit(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
-                                             int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64, ItxAccumLayout L,
-                                             uint32_t *__restrict__ keys0, uint32_t *__restrict__ blk_cnt,
-                                             uint32_t *__restrict__ pcount, uint32_t n_part)
-{
-    extern __shared__ uint32_t smem[];
-    uint32_t *s_cnt = smem;                                   // [16]
-    uint32_t *s_cursor = smem + 16;                           // [1] (+pad)
-    uint32_t *s_fc = smem + 32;                               // fam[2F] | cla[2C]
-    const uint32_t nfc = 2 * (T.n_fam + T.n_cla);
-    uint32_t *s_pc = s_fc + nfc;                              // [n_part]
-    for (uint32_t k = threadIdx.x; k < 32 + nfc + n_part; k += PB) smem[k] = 0;
+    extern __shared__ uint32_t s_pc[];                        // [n_part]
+    for (uint32_t k = threadIdx.x; k < n_part; k += PB) s_pc[k] = 0;
     __syncthreads();
-    const size_t begin = (size_t)blockIdx.x * span;
-    size_t end = begin + span;
-    if (end > n) end = n;
-    uint32_t *out = keys0 + 2 * begin;                        // this workgroup's region: at most 2 keys per record
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (size_t base = begin; base < end; base += PB) {
-        const size_t i = base + threadIdx.x;
-        uint32_t cntbits = 0;
-        int32_t hit = -1;
-        ItxDerived d;
-        d.chrom = -1;
-        d.uniq = false;
-        if (i < end) {
-            d = itx_derive(P, T, B, i);
-            cntbits = d.cntbits;
-            if (d.chrom >= 0) hit = itx_classify(T, d.chrom, d.start, d.end, P.min_cov);
-            if (hit >= 0) cntbits |= (1u << 9) | (d.uniq ? (1u << 10) : 0u);
-            if (d_hit_row) d_hit_row[i] = hit >= 0 ? T.orig[hit] : -1;
+    const uint32_t total = blk_cnt[blockIdx.x];
+    const uint32_t *in = keys0 + 2 * (size_t)blockIdx.x * span;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long above = ~(((1ull << lane) - 1ull) << 1 | 1ull);      // lanes strictly above this one
+    const uint32_t rounds = (total + PB - 1) / PB;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t idx = r * PB + threadIdx.x;
+        const bool has = idx < total;
+        const uint32_t p = has ? in[idx] >> (2 + ITX_LOGW) : 0xffffffffu;
+        const uint32_t pp = (uint32_t)__shfl_up((int32_t)p, 1, 64);
+        const bool st = has && (lane == 0 || pp != p);          // first lane of a run of equal partitions
+        const unsigned long long m_st = __ballot(st), m_has = __ballot(has);
+        if (st) {
+            const unsigned long long stop = (m_st | ~m_has) & above;
+            const uint32_t e = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
+            atomicAdd(&s_pc[p], e - lane);
         }
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-            if (k == 8) continue;
-            const unsigned long long m = __ballot((cntbits >> k) & 1u);
-            if (lane == 0 && m) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
-        }
-        uint32_t kA = 0, kB = 0;
-        bool hasA = hit >= 0, hasB = false;
-        if (hasA) {
-            const ItxIv r = T.iv[hit];
-            uint32_t first;
-            const uint32_t nc = itx_cov_range(r, d.start, d.end, &first);
-            const uint32_t u = d.uniq ? 1u : 0u;
-            if (nc) {
-                kA = (first << 2) | u;
-                kB = ((first + nc) << 2) | 2u | u;
-                hasB = true;
-            } else {
-                kA = (r.zslot << 2) | u;
-            }
-            const uint32_t fam = r.famcla >> 16, cla = r.famcla & 0xffffu;
-            atomicAdd(&s_fc[fam], 1u);
-            atomicAdd(&s_fc[2 * T.n_fam + cla], 1u);
-            if (u) {
-                atomicAdd(&s_fc[T.n_fam + fam], 1u);
-                atomicAdd(&s_fc[2 * T.n_fam + T.n_cla + cla], 1u);
-            }
-        }
-        // compaction: wave-level ranks, one LDS add per wave for the region cursor
-        const unsigned long long mA = __ballot(hasA), mB = __ballot(hasB);
-        const uint32_t nA = (uint32_t)__popcll(mA), nB = (uint32_t)__popcll(mB);
-        uint32_t wbase = 0;
-        if (lane == 0 && (nA + nB)) wbase = atomicAdd(s_cursor, nA + nB);
-        wbase = __shfl(wbase, 0, 64);
-        if (hasA) out[wbase + (uint32_t)__popcll(mA & lt)] = kA;
-        if (hasB) out[wbase + nA + (uint32_t)__popcll(mB & lt)] = kB;
-        lds_count_partition(s_pc, kA >> (2 + ITX_LOGW), hasA);
-        lds_count_partition(s_pc, kB >> (2 + ITX_LOGW), hasB);
     }
     __syncthreads();
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = *s_cursor;
-    if (threadIdx.x < 16 && s_cnt[threadIdx.x])
-        atomicAdd((unsigned long long *)&u64[L.cnt + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    for (uint32_t k = threadIdx.x; k < nfc; k += PB) {
-        const uint32_t v = s_fc[k];
-        if (v) atomicAdd((unsigned long long *)&u64[L.fam + k], (unsigned long long)v);
-    }
     for (uint32_t k = threadIdx.x; k < n_part; k += PB) {
         const uint32_t v = s_pc[k];
         if (v) atomicAdd(&pcount[k], v);
@@ -351,18 +276,14 @@ int itx_part_run(ItxPartWork *w, const ItxDevTable &T, const ItxRunParams &P, co
         itx_set_error("partition path: batch of %zu exceeds capacity %zu", n, w->cap);
         return ITX_E_ARG;
     }
-    // every workgroup takes one contiguous span of records (a multiple of the workgroup size)
-    size_t span = (n + w->n_blocks - 1) / w->n_blocks;
-    span = (span + PB - 1) / PB * PB;
+    // every workgroup takes one contiguous span of records (a multiple of the stream tile)
+    size_t span = (n + w->max_blocks - 1) / w->max_blocks;
+    span = (span + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
     const uint32_t nb = (uint32_t)((n + span - 1) / span);
     ITX_HIP(hipMemsetAsync(w->pcount, 0, (size_t)w->n_part * 4, st));
-    const size_t sh_emit = (32 + 2 * (size_t)(T.n_fam + T.n_cla) + w->n_part) * 4;
-    if (sh_emit > 64 * 1024) {
-        itx_set_error("partition path: %zu bytes of LDS needed by k_emit (families/classes/partitions too many)", sh_emit);
-        return ITX_E_LIMIT;
-    }
-    hipLaunchKernelGGL(k_emit, dim3(nb), dim3(PB), sh_emit, st, T, P, B, n, span, d_hit_row, u64, L, w->keys0, w->blk_cnt, w->pcount,
-                       w->n_part);
+    int rc = itx_launch_stream(ITX_DO_EMIT, T, P, B, n, span, nb, d_hit_row, u64, u32, L, w->keys0, w->blk_cnt, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_count, dim3(nb), dim3(PB), (size_t)w->n_part * 4, st, w->keys0, w->blk_cnt, span, w->pcount, w->n_part);
     ITX_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, w->pcount, w->n_part, w->pbase, w->cursor, w->items, w->n_items);
     ITX_HIP(hipGetLastError());

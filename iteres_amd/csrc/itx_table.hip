@@ -1,15 +1,19 @@
 // itx_table.hip — builds the device-resident repeat table.
 //
 // Stands in for rmsk2binKeeperHash's per-chromosome binKeeper (generic.c:1613-1626,
-// cuskent/binRange.c:140-186). The reference answers "which rows overlap [start,end)" by walking
-// six levels of LIFO bin lists; the order in which it RETURNS the hits matters (generic.c:950-960
-// picks "the last hit whose coverage beats the previous hit's"). Here the rows of a chromosome are
-// laid out as one start-sorted array with
-//   * a binned start index (bidx) for an O(1) upper bound on the candidate range,
+// cuskent/binRange.c:140-186) plus each row's links into hashRep/hashFam/hashCla (generic.c:1631-1693).
+// The reference answers "which rows overlap [start,end)" by walking six levels of LIFO bin lists; the
+// order in which it RETURNS the hits matters (generic.c:950-960 picks "the last hit whose coverage
+// beats the previous hit's"). Here the rows of a chromosome are one start-sorted array with
+//   * a binned index `bl` (per 2^shift bp: first row starting in/after the bin, first row whose
+//     prefix-max end passes the bin start) bounding the candidate range from both sides in O(1),
 //   * a prefix-maximum of the ends (pmax_e) as the scan-stop bound, and
 //   * each row's RANK in binKeeperFind's return order (level coarse->fine, bin descending,
 //     insertion ascending — cuskent/binRange.c:209-225) so the kernel can replay the best-hit rule
 //     exactly without the bin lists.
+// Accumulation is per UNIT = distinct (repName, repFamily, repClass) triple of a row: the reference bumps
+// the row's own family/class entries (generic.c:1010-1024), and repName -> family is not functional in
+// rmsk, so counting per triple and summing at finish gives all three stat tables from one accumulator.
 #include "itx_common.h"
 
 #include <algorithm>
@@ -29,7 +33,7 @@ void itx_set_error(const char *fmt, ...)
     va_end(ap);
 }
 extern "C" const char *itx_last_error(void) { return g_err; }
-extern "C" int itx_abi_version(void) { return 1000; }
+extern "C" int itx_abi_version(void) { return 1001; }
 extern "C" int itx_device_count(void)
 {
     int n = 0;
@@ -58,13 +62,16 @@ static bool bin_of_range(int start, int end, int *level, int *bin)
     return false;
 }
 
-template <class T> static T *carve(char *base, size_t &off, size_t count)
-{
-    off = (off + 255) & ~size_t(255);
-    T *p = reinterpret_cast<T *>(base + off);
-    off += count * sizeof(T);
-    return p;
-}
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes)
+    {
+        off = (off + 255) & ~size_t(255);
+        size_t o = off;
+        off += bytes;
+        return o;
+    }
+};
 
 extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_t *chrom_size, int n_chrom,
                                 const uint32_t *rep_len, uint32_t n_rep, uint32_t n_fam, uint32_t n_cla, int device,
@@ -78,33 +85,12 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         itx_set_error("itx_table_create: %zu rows exceed the 2^31 row limit", n_rows);
         return ITX_E_LIMIT;
     }
-    if (n_fam > 65535 || n_cla > 65535) {
-        itx_set_error("itx_table_create: more than 65535 families/classes (%u/%u)", n_fam, n_cla);
-        return ITX_E_LIMIT;
-    }
     for (int c = 0; c < n_chrom; c++)
         if (chrom_size[c] < 0 || chrom_size[c] > 0x7fffffffLL) {
             itx_set_error("itx_table_create: chromosome %d size %lld outside int range (binKeeperNew takes int)", c,
                           (long long)chrom_size[c]);
             return ITX_E_LIMIT;
         }
-    // slot space: rep_len+1 slots per name
-    std::vector<uint32_t> covslot(n_rep + 1);
-    std::vector<uint64_t> covoff(n_rep + 1);
-    uint64_t slots = 0, cov = 0;
-    for (uint32_t r = 0; r < n_rep; r++) {
-        covslot[r] = (uint32_t)slots;
-        covoff[r] = cov;
-        slots += (uint64_t)rep_len[r] + 1;
-        cov += rep_len[r];
-        if (slots >= (1ull << 30)) {
-            itx_set_error("itx_table_create: consensus slot space exceeds 2^30");
-            return ITX_E_LIMIT;
-        }
-    }
-    covslot[n_rep] = (uint32_t)slots;
-    covoff[n_rep] = cov;
-
     // validate rows as binKeeperAdd would, bucket by chromosome
     std::vector<uint32_t> chrom_cnt(n_chrom + 1, 0);
     std::vector<int> lvl(n_rows), bin(n_rows);
@@ -124,9 +110,50 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         }
         chrom_cnt[r.chrom + 1]++;
     }
+    // units: distinct (rep, fam, cla) triples, ordered by (rep, fam, cla)
+    std::vector<uint32_t> uorder(n_rows);
+    std::iota(uorder.begin(), uorder.end(), 0u);
+    std::sort(uorder.begin(), uorder.end(), [&](uint32_t a, uint32_t b) {
+        const itx_row &x = rows[a], &y = rows[b];
+        if (x.rep != y.rep) return x.rep < y.rep;
+        if (x.fam != y.fam) return x.fam < y.fam;
+        return x.cla < y.cla;
+    });
+    std::vector<uint32_t> unit_of_row(n_rows);
+    std::vector<uint4> unit_ids;
+    for (size_t k = 0; k < n_rows; k++) {
+        const itx_row &r = rows[uorder[k]];
+        if (k == 0 || unit_ids.back().x != r.rep || unit_ids.back().y != r.fam || unit_ids.back().z != r.cla)
+            unit_ids.push_back(make_uint4(r.rep, r.fam, r.cla, 0));
+        unit_of_row[uorder[k]] = (uint32_t)unit_ids.size() - 1;
+    }
+    const uint32_t n_units = (uint32_t)unit_ids.size();
+    std::vector<uint64_t> covoff(n_rep + 1);
+    uint64_t cov = 0;
+    for (uint32_t r = 0; r < n_rep; r++) {
+        covoff[r] = cov;
+        cov += rep_len[r];
+    }
+    covoff[n_rep] = cov;
+    std::vector<uint32_t> unit_slot(n_units + 1);
+    std::vector<uint64_t> unit_covoff(n_units);
+    uint64_t slots = 0;
+    for (uint32_t u = 0; u < n_units; u++) {
+        unit_slot[u] = (uint32_t)slots;
+        slots += (uint64_t)rep_len[unit_ids[u].x] + 1;
+        if (slots >= (1ull << 30)) {
+            itx_set_error("itx_table_create: consensus slot space exceeds 2^30");
+            return ITX_E_LIMIT;
+        }
+        unit_covoff[u] = covoff[unit_ids[u].x];
+        const bool prev_same = u > 0 && unit_ids[u - 1].x == unit_ids[u].x;
+        const bool next_same = u + 1 < n_units && unit_ids[u + 1].x == unit_ids[u].x;
+        unit_ids[u].w = (prev_same || next_same) ? 0u : 1u;     // solo: the name's only unit
+    }
+    unit_slot[n_units] = (uint32_t)slots;
+
     std::vector<uint32_t> chrom_off(n_chrom + 1, 0);
     for (int c = 0; c < n_chrom; c++) chrom_off[c + 1] = chrom_off[c] + chrom_cnt[c + 1];
-
     // start-sorted order per chromosome (stable in file order)
     std::vector<uint32_t> order(n_rows);
     {
@@ -151,15 +178,15 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
             for (uint32_t k = lo; k < hi; k++) rank_of_row[canon[k]] = k - lo;
         }
     }
-    // bin shift: finest power of two >= 128 bp that keeps the index within ~4 entries per row
+    // bin width: about one row per bin (128 bp .. 128 kb)
     uint64_t genome = 0;
     for (int c = 0; c < n_chrom; c++) genome += (uint64_t)chrom_size[c];
     int shift = 7;
-    uint64_t budget = std::max<uint64_t>(4 * (uint64_t)n_rows, 1u << 16);
+    uint64_t budget = std::max<uint64_t>((uint64_t)n_rows + (uint64_t)n_rows / 2, 1u << 16);
     while (shift < 17 && (genome >> shift) + 2 * (uint64_t)n_chrom > budget) shift++;
     std::vector<uint32_t> bin_off(n_chrom + 1, 0);
     for (int c = 0; c < n_chrom; c++) bin_off[c + 1] = bin_off[c] + (uint32_t)(((uint64_t)chrom_size[c] >> shift) + 2);
-    std::vector<uint32_t> bidx(bin_off[n_chrom]);
+    std::vector<uint2> bl(bin_off[n_chrom]);
     std::vector<ItxIv> iv(n_rows);
     std::vector<uint32_t> rnk(n_rows);
     std::vector<int32_t> orig(n_rows);
@@ -176,20 +203,22 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
             pm = std::max(pm, d.e);
             d.pmax_e = pm;
             d.cs = r.cons_start;
-            uint32_t len = rep_len[r.rep];
+            const uint32_t len = rep_len[r.rep];
+            const uint32_t u = unit_of_row[order[k]];
             d.jcap = std::min(r.cons_end, len);
-            d.covslot = covslot[r.rep];
-            d.zslot = covslot[r.rep] + len;
-            d.famcla = (r.fam << 16) | r.cla;
+            d.covslot = unit_slot[u];
+            d.zslot = unit_slot[u] + len;
+            d.unit = u;
             rnk[k] = rank_of_row[order[k]];
             orig[k] = (int32_t)order[k];
         }
         uint32_t nb = bin_off[c + 1] - bin_off[c];
-        uint32_t k = lo;
+        uint32_t k = lo, m = lo;
         for (uint32_t b = 0; b < nb; b++) {
             int64_t bound = (int64_t)b << shift;
-            while (k < hi && (int64_t)iv[k].s < bound) k++;
-            bidx[bin_off[c] + b] = k;
+            while (k < hi && (int64_t)iv[k].s < bound) k++;          // first row starting at or after the bin
+            while (m < hi && (int64_t)iv[m].pmax_e <= bound) m++;    // first row whose prefix-max end passes the bin start
+            bl[bin_off[c] + b] = make_uint2(k, m);
         }
     }
 
@@ -199,6 +228,35 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         return ITX_E_NO_DEVICE;
     }
     ITX_HIP(hipSetDevice(device));
+    Carver cv;
+    const size_t o_iv = cv.take((n_rows + 1) * sizeof(ItxIv));
+    const size_t o_rank = cv.take((n_rows + 1) * 4);
+    const size_t o_orig = cv.take((n_rows + 1) * 4);
+    const size_t o_bl = cv.take((bl.size() + 1) * sizeof(uint2));
+    const size_t o_uslot = cv.take(((size_t)n_units + 1) * 4);
+    const size_t o_uids = cv.take(((size_t)n_units + 1) * sizeof(uint4));
+    const size_t o_ucov = cv.take(((size_t)n_units + 1) * 8);
+    const size_t total = cv.take(0) + 256;
+    char *base = nullptr;
+    hipError_t he = hipMalloc((void **)&base, total);
+    if (he != hipSuccess) {
+        itx_set_error("itx_table_create: hipMalloc(%zu) failed: %s", total, hipGetErrorString(he));
+        return ITX_E_NOMEM;
+    }
+    auto up = [&](size_t off, const void *src, size_t bytes) -> bool {
+        if (bytes == 0) return true;
+        he = hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice);
+        return he == hipSuccess;
+    };
+    bool ok = up(o_iv, iv.data(), iv.size() * sizeof(ItxIv)) && up(o_rank, rnk.data(), rnk.size() * 4) &&
+              up(o_orig, orig.data(), orig.size() * 4) && up(o_bl, bl.data(), bl.size() * sizeof(uint2)) &&
+              up(o_uslot, unit_slot.data(), unit_slot.size() * 4) && up(o_uids, unit_ids.data(), unit_ids.size() * sizeof(uint4)) &&
+              up(o_ucov, unit_covoff.data(), unit_covoff.size() * 8);
+    if (!ok) {
+        itx_set_error("itx_table_create: upload failed: %s", hipGetErrorString(he));
+        (void)hipFree(base);
+        return ITX_E_NO_DEVICE;
+    }
     itx_table *t = new itx_table();
     memset(t, 0, sizeof *t);
     t->device = device;
@@ -208,76 +266,30 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     t->n_rep = n_rep;
     t->n_fam = n_fam;
     t->n_cla = n_cla;
+    t->n_units = n_units;
     t->n_slots = (uint32_t)slots;
     t->cov_len = cov;
-    // one allocation, carved
-    size_t off = 0;
-    char *nullbase = nullptr;
-    ItxIv *o_iv = carve<ItxIv>(nullbase, off, n_rows + 1);
-    uint32_t *o_rank = carve<uint32_t>(nullbase, off, n_rows + 1);
-    int32_t *o_orig = carve<int32_t>(nullbase, off, n_rows + 1);
-    uint32_t *o_coff = carve<uint32_t>(nullbase, off, n_chrom + 1);
-    uint32_t *o_boff = carve<uint32_t>(nullbase, off, n_chrom + 1);
-    uint32_t *o_bidx = carve<uint32_t>(nullbase, off, bidx.size() + 1);
-    int32_t *o_csz = carve<int32_t>(nullbase, off, n_chrom + 1);
-    uint32_t *o_rlen = carve<uint32_t>(nullbase, off, n_rep + 1);
-    uint32_t *o_cslot = carve<uint32_t>(nullbase, off, n_rep + 1);
-    uint64_t *o_covoff = carve<uint64_t>(nullbase, off, n_rep + 1);
-    size_t total = (off + 255) & ~size_t(255);
-    char *base = nullptr;
-    hipError_t he = hipMalloc((void **)&base, total);
-    if (he != hipSuccess) {
-        itx_set_error("itx_table_create: hipMalloc(%zu) failed: %s", total, hipGetErrorString(he));
-        delete t;
-        return ITX_E_NOMEM;
-    }
     t->d_all = base;
     t->table_bytes = total;
-#define DEV(p) reinterpret_cast<decltype(p)>(base + reinterpret_cast<size_t>(p))
-#define UP(dst, vec)                                                                                   \
-    if (!(vec).empty()) {                                                                              \
-        he = hipMemcpy(DEV(dst), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice); \
-        if (he != hipSuccess) {                                                                        \
-            itx_set_error("itx_table_create: upload failed: %s", hipGetErrorString(he));               \
-            (void)hipFree(base);                                                                           \
-            delete t;                                                                                  \
-            return ITX_E_NO_DEVICE;                                                                    \
-        }                                                                                              \
-    }
-    std::vector<uint32_t> rlen(rep_len, rep_len + n_rep);
-    UP(o_iv, iv);
-    UP(o_rank, rnk);
-    UP(o_orig, orig);
-    UP(o_coff, chrom_off);
-    UP(o_boff, bin_off);
-    UP(o_bidx, bidx);
-    UP(o_csz, csize);
-    UP(o_rlen, rlen);
-    UP(o_cslot, covslot);
-    UP(o_covoff, covoff);
-    t->dev.iv = DEV(o_iv);
-    t->dev.rank = DEV(o_rank);
-    t->dev.orig = DEV(o_orig);
-    t->dev.chrom_off = DEV(o_coff);
-    t->dev.bin_off = DEV(o_boff);
-    t->dev.bidx = DEV(o_bidx);
-    t->dev.chrom_size = DEV(o_csz);
-    t->dev.n_chrom = n_chrom;
+    t->dev.iv = (const ItxIv *)(base + o_iv);
+    t->dev.rank = (const uint32_t *)(base + o_rank);
+    t->dev.orig = (const int32_t *)(base + o_orig);
+    t->dev.bl = (const uint2 *)(base + o_bl);
     t->dev.shift = shift;
     t->dev.n_rows = (uint32_t)n_rows;
-    t->dev.n_rep = n_rep;
-    t->dev.n_fam = n_fam;
-    t->dev.n_cla = n_cla;
+    t->dev.n_units = n_units;
     t->dev.n_slots = (uint32_t)slots;
-    t->d_rep_len = DEV(o_rlen);
-    t->d_covslot = DEV(o_cslot);
-    t->d_covoff = DEV(o_covoff);
-#undef UP
-#undef DEV
+    t->d_unit_slot = (uint32_t *)(base + o_uslot);
+    t->d_unit_ids = (uint4 *)(base + o_uids);
+    t->d_unit_covoff = (uint64_t *)(base + o_ucov);
     t->h_rep_len = (uint32_t *)malloc(sizeof(uint32_t) * (n_rep + 1));
-    t->h_covslot = (uint32_t *)malloc(sizeof(uint32_t) * (n_rep + 1));
     if (n_rep) memcpy(t->h_rep_len, rep_len, sizeof(uint32_t) * n_rep);
-    memcpy(t->h_covslot, covslot.data(), sizeof(uint32_t) * (n_rep + 1));
+    t->h_chrom_off = (uint32_t *)malloc(sizeof(uint32_t) * (n_chrom + 1));
+    t->h_bin_off = (uint32_t *)malloc(sizeof(uint32_t) * (n_chrom + 1));
+    t->h_chrom_size = (int32_t *)malloc(sizeof(int32_t) * (n_chrom + 1));
+    memcpy(t->h_chrom_off, chrom_off.data(), sizeof(uint32_t) * (n_chrom + 1));
+    memcpy(t->h_bin_off, bin_off.data(), sizeof(uint32_t) * (n_chrom + 1));
+    if (n_chrom) memcpy(t->h_chrom_size, csize.data(), sizeof(int32_t) * n_chrom);
     *out = t;
     return ITX_OK;
 }
@@ -290,7 +302,9 @@ extern "C" void itx_table_destroy(itx_table *t)
         (void)hipFree(t->d_all);
     }
     free(t->h_rep_len);
-    free(t->h_covslot);
+    free(t->h_chrom_off);
+    free(t->h_bin_off);
+    free(t->h_chrom_size);
     delete t;
 }
 
@@ -300,15 +314,14 @@ extern "C" int itx_table_get_info(const itx_table *t, itx_table_info *o)
         itx_set_error("itx_table_get_info: null argument");
         return ITX_E_ARG;
     }
-    ItxAccumLayout L = itx_accum_layout(t->n_rep, t->n_fam, t->n_cla, t->n_slots, t->n_rows);
     memset(o, 0, sizeof *o);
     o->n_rows = t->n_rows;
     o->n_rep = t->n_rep;
     o->n_fam = t->n_fam;
     o->n_cla = t->n_cla;
     o->cov_len = t->cov_len;
-    o->n_u64 = L.n_u64;
-    o->n_u32 = L.n_u32;
+    o->n_units = t->n_units;
+    o->n_slots = t->n_slots;
     o->table_bytes = t->table_bytes;
     o->n_chrom = t->n_chrom;
     o->bin_shift = t->shift;

@@ -21,6 +21,7 @@ EXPORTS = [
     "itx_table_get_info", "itx_table_cov_offsets", "itx_engine_create", "itx_engine_destroy", "itx_engine_set_tidmap",
     "itx_engine_staging", "itx_engine_submit_slot", "itx_engine_wait_slot", "itx_engine_submit_device",
     "itx_engine_classify_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
+    "itx_engine_partial_size", "itx_engine_export_partial", "itx_engine_finish_partial",
 ]
 
 
@@ -40,7 +41,7 @@ assert ROW_DTYPE.itemsize == C.sizeof(Row) == 32
 
 class TableInfo(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("n_rep", C.c_uint64), ("n_fam", C.c_uint64), ("n_cla", C.c_uint64),
-                ("cov_len", C.c_uint64), ("n_u64", C.c_uint64), ("n_u32", C.c_uint64), ("table_bytes", C.c_uint64),
+                ("cov_len", C.c_uint64), ("n_units", C.c_uint64), ("n_slots", C.c_uint64), ("table_bytes", C.c_uint64),
                 ("n_chrom", C.c_int32), ("bin_shift", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
@@ -83,7 +84,10 @@ def load():
     L.itx_table_destroy.restype = None
     L.itx_table_get_info.argtypes = [C.c_void_p, C.POINTER(TableInfo)]
     L.itx_table_cov_offsets.argtypes = [C.c_void_p, C.c_void_p]
-    L.itx_engine_create.argtypes = [C.c_void_p, C.POINTER(Params), C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.itx_engine_create.argtypes = [C.c_void_p, C.POINTER(Params), C.c_size_t, C.POINTER(C.c_void_p)]
+    L.itx_engine_partial_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.itx_engine_export_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.itx_engine_finish_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Result)]
     L.itx_engine_destroy.argtypes = [C.c_void_p]
     L.itx_engine_destroy.restype = None
     L.itx_engine_set_tidmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -157,7 +161,7 @@ class Table:
 
 
 class Engine:
-    def __init__(self, table: Table, params: dict | None = None, batch_capacity: int = 1 << 20, u64_accum_ptr=None, u32_accum_ptr=None):
+    def __init__(self, table: Table, params: dict | None = None, batch_capacity: int = 1 << 20):
         L = load()
         q = dict(mapq_min=10, min_cov=0.0001, extension=150, isize_max=500, treat_pe_as_se=False, discard_half_mapped=False,
                  filter_mode=False, accum=ACCUM_DEFAULT)
@@ -167,8 +171,7 @@ class Engine:
                              MODE_FILTER if q.get("filter_mode") else MODE_STAT, int(q["accum"]))
         self.table = table
         h = C.c_void_p()
-        _chk(L.itx_engine_create(table._h, C.byref(self.params), int(batch_capacity), u64_accum_ptr, u32_accum_ptr, C.byref(h)),
-             "itx_engine_create")
+        _chk(L.itx_engine_create(table._h, C.byref(self.params), int(batch_capacity), C.byref(h)), "itx_engine_create")
         self._h = h
         self.capacity = int(batch_capacity)
 
@@ -228,13 +231,30 @@ class Engine:
     def reset(self):
         _chk(load().itx_engine_reset(self._h), "itx_engine_reset")
 
-    def finish(self):
+    def _result_arrays(self):
         t = self.table
         res = {"cnt": np.zeros(13, np.uint64), "rep_cnt": np.zeros(2 * t.n_rep, np.uint64), "fam_cnt": np.zeros(2 * t.n_fam, np.uint64),
                "cla_cnt": np.zeros(2 * t.n_cla, np.uint64), "cov": np.zeros(int(t.info.cov_len), np.uint32),
                "cov_uniq": np.zeros(int(t.info.cov_len), np.uint32), "locus_cnt": np.zeros(max(t.n_rows, 1), np.uint32)}
         r = Result(*(_p(res[k]) for k in ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq", "locus_cnt")))
+        return res, r
+
+    def finish(self):
+        res, r = self._result_arrays()
         _chk(load().itx_engine_finish(self._h, C.byref(r)), "itx_engine_finish")
+        return res
+
+    def partial_size(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _chk(load().itx_engine_partial_size(self._h, C.byref(a), C.byref(b)), "itx_engine_partial_size")
+        return int(a.value), int(b.value)
+
+    def export_partial(self, u64_ptr, u32_ptr, stream=None):
+        _chk(load().itx_engine_export_partial(self._h, u64_ptr, u32_ptr, stream), "itx_engine_export_partial")
+
+    def finish_partial(self, u64_ptr, u32_ptr):
+        res, r = self._result_arrays()
+        _chk(load().itx_engine_finish_partial(self._h, u64_ptr, u32_ptr, C.byref(r)), "itx_engine_finish_partial")
         return res
 
     def stats(self):

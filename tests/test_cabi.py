@@ -31,13 +31,13 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_error_paths(lib):
-    assert lib.itx_abi_version() == 1000
+    assert lib.itx_abi_version() == 1001
     assert lib.itx_table_get_info(None, None) == -1                 # ITX_E_ARG
     assert b"null" in lib.itx_last_error()
     h = C.c_void_p()
     bad = C.c_size_t(0)
     assert lib.itx_table_create(None, 5, None, 1, None, 0, 0, 0, 0, C.byref(h), C.byref(bad)) == -1
-    assert lib.itx_engine_create(None, None, 0, None, None, C.byref(h)) == -1
+    assert lib.itx_engine_create(None, None, 0, C.byref(h)) == -1
     assert lib.itx_engine_finish(None, None) == -1
 
 

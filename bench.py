@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — M alignments/s through the iteres stat hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): a coordinate-sorted 50 M-read synthetic hg38 alignment set against a
+5.5 M-row RepeatMasker-like table (15 k names / 60 families / 20 classes), `iteres stat` defaults
+(-Q 10 -E 150 -c 1e-4), per-base coverage on. The record SoA (tid, pos, end, MAPQ, flags: 14 B/record) is
+resident in HBM when the timed region starts. One "step" = one pass of the hot path over the batch:
+classify + key emit -> partition -> LDS histograms into the device accumulators. Weak scaling: every rank owns
+its own 50 M-read shard and a replica of the table; the single end-of-stream exchange — export of the compact
+partial and one RCCL all-reduce (sum) of it — is INSIDE the timed region, after the K steps.
+
+One JSON line on rank 0. `roofline` is for the dominant kernel (k_stream: derive + classify + key emit), timed
+with HIP events recorded on the submitting stream around that launch, every step of the timed region.
+`cpu_baseline` (rank 0, N = 1): the oracle — our single-threaded C restatement of the reference loop — on a
+bounded sample of the same reads (test infrastructure used as the checker/baseline only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=50_000_000)
+    ap.add_argument("--rows", type=int, default=5_500_000)
+    ap.add_argument("--accum", type=int, default=0, help="0 default (partition), 1 atomic, 2 partition")
+    ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records the CPU baseline runs over (0 = skip)")
+    ap.add_argument("--verify", type=int, default=1)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import build
+    if rank == 0:
+        build()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    from iteres_amd import engine as eng, synth
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---------------------------------------------------------------- workload
+    t0 = time.time()
+    scale = a.rows / 5_500_000
+    chroms = synth.HG38_CHROMS if scale == 1 else [(n, max(int(s * scale), 1000)) for n, s in synth.HG38_CHROMS]
+    tb = synth.make_table(20260101, chroms, a.rows, n_names=15000, n_fams=60, n_clas=20, overlap_frac=0.02)
+    rep_len = np.array([tb.rep_len.get(n, 0) for n in tb.names], np.uint32)
+    rows = eng.make_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
+    cs = np.array([s for _, s in chroms], np.int64)
+    tid, pos, tmpend, mapq, f5 = synth.make_reads_soa(20260102 + rank, chroms, a.reads)
+    table = eng.Table(rows, cs, rep_len, len(tb.fams), len(tb.clas), device=local_rank)
+    e = eng.Engine(table, dict(accum=a.accum), batch_capacity=a.reads)
+    e.set_tidmap(list(range(len(chroms))))
+    d = {k: torch.from_numpy(v).to(dev) for k, v in (("tid", tid), ("pos", pos), ("tmpend", tmpend), ("mapq", mapq), ("flag5", f5))}
+    ptrs = {k: v.data_ptr() for k, v in d.items()}
+    n64, n32 = e.partial_size()
+    p64 = torch.zeros(n64, dtype=torch.int64, device=dev)      # sums are mod 2^64 / 2^32: signed containers are fine
+    p32 = torch.zeros(n32, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    setup_s = time.time() - t0
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- warmup, then K timed steps + the one exchange
+    for _ in range(a.warmup):
+        e.submit_device(ptrs, a.reads, stream=stream)
+    e.sync()
+    e.reset()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        e.submit_device(ptrs, a.reads, stream=stream)
+    e.export_partial(p64.data_ptr(), p32.data_ptr(), stream=stream)
+    if world > 1:
+        dist.all_reduce(p64, op=dist.ReduceOp.SUM)
+        dist.all_reduce(p32, op=dist.ReduceOp.SUM)
+    fence()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    st = e.stats()
+
+    # ---------------------------------------------------------------- results from the reduced partial (untimed)
+    res = e.finish_partial(p64.data_ptr(), p32.data_ptr())
+    total_reads = a.reads * a.steps * world
+    checks = {}
+    if a.verify:
+        checks["cnt0_equals_records"] = bool(int(res["cnt"][0]) == total_reads)
+        checks["rep_sum_equals_cnt9"] = bool(int(res["rep_cnt"][: len(rep_len)].sum()) == int(res["cnt"][9]))
+        checks["fam_sum_equals_cnt9"] = bool(int(res["fam_cnt"][: len(tb.fams)].sum()) == int(res["cnt"][9]))
+        checks["cla_uniq_sum_equals_cnt10"] = bool(int(res["cla_cnt"][len(tb.clas):].sum()) == int(res["cnt"][10]))
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / a.steps
+        value = total_reads / elapsed / 1e6
+        stream_ms = st["stage_ms"][0] / max(st["submits"], 1)
+        keys = st["keys"]
+        # algorithmic bytes of one k_stream launch: 14 B per record in, 4 B per key out,
+        # plus the table rows (32 B) and binned index (8 B/bin) once per launch
+        table_once = int(table.info.n_rows) * 32 + int(sum(s for _, s in chroms) >> int(table.info.bin_shift)) * 8
+        alg_bytes = 14 * a.reads + 4 * keys + table_once
+        achieved = alg_bytes / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get("k_stream_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "M alignments/sec through `iteres stat` hot path (hg38 rmsk), records resident in HBM",
+            "value": round(value, 3), "unit": "M alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 50M-read coordinate-sorted synthetic hg38 alignments vs 5.5M-row rmsk, iteres stat defaults, per-base coverage on",
+                       "reads_per_gpu_per_step": a.reads, "rmsk_rows": int(table.info.n_rows), "rep_names": len(rep_len),
+                       "consensus_slots": int(table.info.n_slots), "accumulate": "partition" if a.accum in (0, 2) else "atomic",
+                       "exchange": "1 RCCL all-reduce of the partial after the last step (inside the timed region)" if world > 1 else "partial export only (N=1)"},
+            "roofline": {"bound": "hbm", "kernel": "k_stream<EMIT> (derive + classify + key emit + partition count)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "avg_launch_ms": round(stream_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "stage_ms_per_step": {k: round(v / max(st["submits"], 1), 4) for k, v in zip(("stream", "plan", "scatter", "hist"), st["stage_ms"])}},
+            "checks": checks,
+            "hits_fraction": round(int(res["cnt"][9]) / max(total_reads, 1), 4),
+            "setup_s": round(setup_s, 1),
+        }
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and a.cpu_sample > 0:
+        from oracle import binding as orc
+        m = min(a.cpu_sample, a.reads)
+        ot = orc.OracleTable(cs, rep_len, len(tb.fams), len(tb.clas))
+        ot.add_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
+        flag16 = np.where(f5[:m] & 8, 16, 0).astype(np.uint16)
+        t2 = time.perf_counter()
+        want = ot.run({}, list(range(len(chroms))), tid[:m], pos[:m], tmpend[:m], mapq[:m], flag16, want_hits=False)
+        cpu_s = time.perf_counter() - t2
+        out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "M alignments/s", "cores": 1, "kind": "port",
+                               "sample": f"first {m} records of the same batch, oracle/liboracle.so (single-threaded C restatement of generic.c:745-1036), {cpu_s:.1f} s"}
+        if a.verify:
+            # the same sample through the GPU path must give the oracle's numbers exactly
+            e.reset()
+            e.submit_device(ptrs, m, stream=stream)
+            got = e.finish()
+            out["checks"]["sample_matches_oracle"] = bool(all(np.array_equal(got[k], want[k]) for k in ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq")))
+        ot.close()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    e.close()
+    table.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

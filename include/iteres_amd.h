@@ -185,9 +185,12 @@ int itx_engine_finish_partial(itx_engine *e, const void *d_u64, const void *d_u3
  * submitting stream around each submit_device/submit_slot (milliseconds), and the number of
  * records classified. */
 typedef struct itx_stats {
-    double kernel_ms;
+    double kernel_ms;             /* all kernels of all submits                                        */
     uint64_t records, hits;
-    uint64_t reserved[5];
+    double stage_ms[5];           /* partition path, summed over submits: [0] stream (derive + classify + */
+                                  /* key emit + partition count), [1] plan, [2] scatter, [3] hist, [4] 0  */
+                                  /* — HIP events recorded between the launches on the submitting stream  */
+    uint64_t submits, keys;       /* number of submits; keys emitted (partition path)                   */
 } itx_stats;
 int itx_engine_get_stats(itx_engine *e, itx_stats *out);
 

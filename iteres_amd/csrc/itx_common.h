@@ -116,9 +116,17 @@ struct ItxDevBatch {
 // accumulates with global atomics (stat: A/B arrays, filter: per-locus counts) or emits keys.
 enum { ITX_DO_CLASSIFY = 0, ITX_DO_ATOMIC_STAT = 1, ITX_DO_ATOMIC_LOCUS = 2, ITX_DO_EMIT = 3 };
 #define ITX_STREAM_TILE 1024u      // records per workgroup iteration (4 waves x 64 lanes x 4 records)
+#define ITX_PART_SUB 8u            // sub-cursors per partition (partition path)
+// What the emitting launch needs to know about the partition path's bookkeeping.
+struct ItxEmitPlan {
+    uint32_t *subcur;   // [n_part * ITX_PART_SUB] zeroed before the launch: keys reserved per (partition, sub-cursor)
+    uint32_t *offm;     // [n_blocks][n_part] offset of each workgroup's keys inside (partition, sub-cursor)
+    uint32_t n_part;
+    uint32_t log_w;     // log2(slots per partition)
+};
 int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, size_t span,
                       unsigned n_blocks, int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, uint32_t *keys0,
-                      uint32_t *blk_cnt, hipStream_t st);
+                      uint32_t *blk_cnt, const ItxEmitPlan &E, hipStream_t st);
 // finish-time kernels (itx_finalize.hip)
 int itx_launch_export(const itx_table *t, int mode, const uint64_t *u64, const uint32_t *u32, const ItxAccumLayout &L, uint64_t *p64,
                       uint32_t *p32, hipStream_t st);

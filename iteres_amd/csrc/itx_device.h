@@ -239,6 +239,24 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
     return v;
 }
 
+// Runs of equal values over the lanes of a wave (every lane must call). Returns whether this lane starts a
+// run; *len = length of the run starting here; *leader = first lane of the run this lane belongs to.
+__device__ __forceinline__ bool wave_run(uint32_t v, bool has, uint32_t lane, uint32_t *len, uint32_t *leader)
+{
+    const uint32_t pv = (uint32_t)__shfl_up((int32_t)v, 1, 64);
+    const unsigned long long m_has = __ballot(has);
+    const bool prev_has = lane != 0 && ((m_has >> (lane - 1)) & 1ull);
+    const bool st = has && (!prev_has || pv != v);            // a lane without a value always breaks the run
+    const unsigned long long m_st = __ballot(st);
+    const unsigned long long below_eq = (((1ull << lane) - 1ull) << 1) | 1ull;          // lanes <= this one
+    const unsigned long long stop = (m_st | ~m_has) & ~below_eq;                         // next run start / gap above
+    const uint32_t e = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
+    *len = e - lane;
+    const unsigned long long mine = m_st & below_eq;                                     // highest start at or below
+    *leader = mine ? 63u - (uint32_t)__clzll((long long)mine) : lane;
+    return st;
+}
+
 // Consensus range a classified read increments (generic.c:991-1007) in slot space:
 // returns n (number of consensus positions) and sets *first to the first slot; n == 0 means the read
 // is counted but adds no coverage.

@@ -38,7 +38,8 @@ struct itx_engine {
     uint32_t *d_cov, *d_cov_uniq, *d_locus_out;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     double kernel_ms;
-    uint64_t records;
+    double stage_ms[5];
+    uint64_t records, submits, keys;
     ItxPartWork *pw;      // scratch of the partition path
     unsigned max_blocks;
 };
@@ -94,7 +95,8 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     e->d_counts = nullptr;
     e->d_cov = e->d_cov_uniq = e->d_locus_out = nullptr;
     e->kernel_ms = 0;
-    e->records = 0;
+    e->records = e->submits = e->keys = 0;
+    memset(e->stage_ms, 0, sizeof e->stage_ms);
     e->pw = nullptr;
     e->max_blocks = 2048;
     if (const char *s = getenv("ITX_STREAM_BLOCKS")) {
@@ -272,11 +274,15 @@ static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_h
         span = (span + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
         const unsigned nb = (unsigned)((n + span - 1) / span);
         const int what = !accumulate ? ITX_DO_CLASSIFY : (e->p.mode == ITX_MODE_STAT ? ITX_DO_ATOMIC_STAT : ITX_DO_ATOMIC_LOCUS);
-        rc = itx_launch_stream(what, e->t->dev, P, B, n, span, nb, d_hit_row, e->u64, e->u32, e->L, nullptr, nullptr, st);
+        const ItxEmitPlan none = {nullptr, nullptr, 0, 0};
+        rc = itx_launch_stream(what, e->t->dev, P, B, n, span, nb, d_hit_row, e->u64, e->u32, e->L, nullptr, nullptr, none, st);
     }
     ITX_HIP(hipEventRecord(b, st));
     e->ev.emplace_back(a, b);
-    if (accumulate) e->records += n;
+    if (accumulate) {
+        e->records += n;
+        e->submits++;
+    }
     return rc;
 }
 
@@ -383,6 +389,11 @@ static void fold_events(itx_engine *e)
         (void)hipEventDestroy(pr.second);
     }
     e->ev.clear();
+    if (e->pw) {
+        uint64_t k = 0;
+        itx_part_fold_stats(e->pw, e->stage_ms, &k);
+        e->keys = k;
+    }
 }
 
 extern "C" int itx_engine_reset(itx_engine *e)
@@ -394,7 +405,8 @@ extern "C" int itx_engine_reset(itx_engine *e)
     ITX_HIP(hipMemset(e->u32, 0, e->L.n_u32 * sizeof(uint32_t)));
     fold_events(e);
     e->kernel_ms = 0;
-    e->records = 0;
+    e->records = e->submits = e->keys = 0;
+    memset(e->stage_ms, 0, sizeof e->stage_ms);
     return ITX_OK;
 }
 
@@ -497,6 +509,9 @@ extern "C" int itx_engine_get_stats(itx_engine *e, itx_stats *out)
     memset(out, 0, sizeof *out);
     out->kernel_ms = e->kernel_ms;
     out->records = e->records;
+    out->submits = e->submits;
+    out->keys = e->keys;
+    memcpy(out->stage_ms, e->stage_ms, sizeof e->stage_ms);
     uint64_t c[16];
     ITX_HIP(hipMemcpy(c, e->u64, sizeof c, hipMemcpyDeviceToHost));
     out->hits = c[9];

@@ -7,12 +7,15 @@
 //
 //   A  k_stream<EMIT> (itx_stream.hip)  1-2 keys per classified record (slot<<2 | isEnd<<1 | uniq),
 //                  written compacted into the workgroup's own region (LDS cursor, no global atomic).
-//   C  k_count     per-partition key counts: run lengths per wave (sorted input gives long runs), LDS
-//                  histogram per workgroup, one global add per touched partition.
-//   S  k_plan      one workgroup: exclusive scan of the counts, scatter cursors, and the work list of
+//   C  (inside A)  per workgroup region: per-partition key counts (run lengths per wave — sorted input
+//                  gives long runs — into an LDS histogram), then ONE reservation per touched partition on
+//                  one of 8 sub-cursors (workgroup id mod 8: the dispatcher deals workgroups round-robin over
+//                  the 8 XCDs, so a sub-cursor is mostly hit from one XCD and no address sees more than
+//                  n_blocks/8 adds); the offsets it got are stored as the region's row of an offset matrix.
+//   S  k_plan      one workgroup: exclusive scan of the 8*P sub-totals -> bases, and the work list of
 //                  (partition, key range) items for H (a partition with more than ITX_CHUNK keys is split).
-//   P  k_scatter   per 4096-key tile: LDS histogram with returning adds (= local ranks), one global
-//                  reservation per touched partition, keys written to their partition's range.
+//   P  k_scatter   per region: cursor[p] = base[p][sub] + offset row in LDS, then every run of equal partitions
+//                  takes its places with one returning LDS add and writes its keys — no global atomics.
 //   H  k_hist      per item: LDS window of the partition's W slots (A|B counts, all:16|uniq:16 packed),
 //                  ds_add per key, then the window is added into the global A/B arrays — plain
 //                  coalesced read-modify-write when the item owns its partition, atomics (few: the
@@ -20,13 +23,17 @@
 //
 // Integer sums only: the result is independent of order, identical to the atomic path and the oracle.
 #include "itx_partition.h"
+#include "itx_device.h"
 
-#define PB 256              // threads per workgroup
+#include <vector>
+
+#define PB 256              // threads per workgroup (count / scatter)
+#define HB 1024             // threads per workgroup (hist): 2 workgroups per CU keep 32 waves in flight
 #define ITX_LOGW 13         // slots per partition (W = 8192): LDS window of k_hist = W * 8 bytes = 64 KiB
 #define ITX_W (1u << ITX_LOGW)
 #define ITX_CHUNK 32768u    // max keys per k_hist item: keeps the packed 16-bit halves from overflowing
-#define ITX_TILE 4096u      // keys per k_scatter tile (16 per thread)
-#define ITX_MAXP 8192u      // partitions the LDS histograms are sized for
+#define ITX_MAXP 4096u      // partitions the LDS histograms / the plan kernel are sized for
+#define ITX_SUB ITX_PART_SUB // sub-cursors per partition
 
 struct ItxPartWork {
     size_t cap;            // records per batch
@@ -35,12 +42,13 @@ struct ItxPartWork {
     uint32_t max_items;
     uint32_t *keys0, *keys1;   // [2*cap]
     uint32_t *blk_cnt;         // [max_blocks] keys emitted by each workgroup
-    uint32_t *pcount;          // [n_part]
-    uint32_t *pbase;           // [n_part+1]
-    uint32_t *cursor;          // [n_part]
+    uint32_t *subcur;          // [n_part*8] sub-totals, then (after k_plan) bases
+    uint32_t *offm;            // [max_blocks][n_part] offset of each region inside (partition, sub)
     uint4    *items;           // [max_items] (partition, begin, end, exclusive)
     uint32_t *n_items;         // [1]
     void *base;
+    std::vector<hipEvent_t> ev;    // 5 events per batch: before stream, after stream, plan, scatter, hist
+    uint64_t keys_last;
 };
 
 static inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -57,15 +65,18 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
     w->cap = cap;
     w->n_part = n_part ? n_part : 1;
     w->max_blocks = 2048;
+    if (const char *s = getenv("ITX_STREAM_BLOCKS")) {
+        const long v = atol(s);
+        if (v >= 1 && v <= 2048) w->max_blocks = (uint32_t)v;
+    }
     w->max_items = w->n_part + (uint32_t)((2 * cap) / ITX_CHUNK) + 2;
     const size_t kcap = 2 * (cap + ITX_STREAM_TILE) * 4 + 64;
     size_t off = 0;
     const size_t o_k0 = off; off = al256(off + kcap);
     const size_t o_k1 = off; off = al256(off + kcap);
     const size_t o_bc = off; off = al256(off + (size_t)w->max_blocks * 4);
-    const size_t o_pc = off; off = al256(off + (size_t)w->n_part * 4);
-    const size_t o_pb = off; off = al256(off + ((size_t)w->n_part + 1) * 4);
-    const size_t o_cu = off; off = al256(off + (size_t)w->n_part * 4);
+    const size_t o_sc = off; off = al256(off + ((size_t)w->n_part * ITX_SUB + 1) * 4);
+    const size_t o_om = off; off = al256(off + (size_t)w->max_blocks * w->n_part * 4);
     const size_t o_it = off; off = al256(off + (size_t)w->max_items * 16);
     const size_t o_ni = off; off = al256(off + 16);
     char *base = nullptr;
@@ -79,9 +90,8 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
     w->keys0 = (uint32_t *)(base + o_k0);
     w->keys1 = (uint32_t *)(base + o_k1);
     w->blk_cnt = (uint32_t *)(base + o_bc);
-    w->pcount = (uint32_t *)(base + o_pc);
-    w->pbase = (uint32_t *)(base + o_pb);
-    w->cursor = (uint32_t *)(base + o_cu);
+    w->subcur = (uint32_t *)(base + o_sc);
+    w->offm = (uint32_t *)(base + o_om);
     w->items = (uint4 *)(base + o_it);
     w->n_items = (uint32_t *)(base + o_ni);
     *out = w;
@@ -92,52 +102,22 @@ void itx_part_destroy(ItxPartWork *w)
 {
     if (!w) return;
     if (w->base) (void)hipFree(w->base);
+    for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     delete w;
 }
 
-// ------------------------------------------------------------------------------------------------ C
-__global__ __launch_bounds__(PB) void k_count(const uint32_t *__restrict__ keys0, const uint32_t *__restrict__ blk_cnt, size_t span,
-                                              uint32_t *__restrict__ pcount, uint32_t n_part)
-{
-    extern __shared__ uint32_t s_pc[];                        // [n_part]
-    for (uint32_t k = threadIdx.x; k < n_part; k += PB) s_pc[k] = 0;
-    __syncthreads();
-    const uint32_t total = blk_cnt[blockIdx.x];
-    const uint32_t *in = keys0 + 2 * (size_t)blockIdx.x * span;
-    const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long above = ~(((1ull << lane) - 1ull) << 1 | 1ull);      // lanes strictly above this one
-    const uint32_t rounds = (total + PB - 1) / PB;
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t idx = r * PB + threadIdx.x;
-        const bool has = idx < total;
-        const uint32_t p = has ? in[idx] >> (2 + ITX_LOGW) : 0xffffffffu;
-        const uint32_t pp = (uint32_t)__shfl_up((int32_t)p, 1, 64);
-        const bool st = has && (lane == 0 || pp != p);          // first lane of a run of equal partitions
-        const unsigned long long m_st = __ballot(st), m_has = __ballot(has);
-        if (st) {
-            const unsigned long long stop = (m_st | ~m_has) & above;
-            const uint32_t e = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
-            atomicAdd(&s_pc[p], e - lane);
-        }
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_part; k += PB) {
-        const uint32_t v = s_pc[k];
-        if (v) atomicAdd(&pcount[k], v);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ S
-__global__ __launch_bounds__(1024) void k_plan(const uint32_t *__restrict__ pcount, uint32_t n_part, uint32_t *__restrict__ pbase,
-                                               uint32_t *__restrict__ cursor, uint4 *__restrict__ items, uint32_t *__restrict__ n_items)
+__global__ __launch_bounds__(1024) void k_plan(uint32_t *__restrict__ subcur, uint32_t n_part, uint4 *__restrict__ items,
+                                               uint32_t *__restrict__ n_items)
 {
-    // n_part <= 8192: each of 1024 threads owns up to 8 consecutive partitions
+    // n_part <= 4096: each of 1024 threads owns up to 4 consecutive partitions (8 sub-totals each)
     __shared__ uint32_t s_k[1024], s_i[1024];
     const uint32_t per = (n_part + 1023) / 1024;
     const uint32_t p0 = threadIdx.x * per;
     uint32_t keys = 0, its = 0;
     for (uint32_t p = p0; p < p0 + per && p < n_part; p++) {
-        const uint32_t c = pcount[p];
+        uint32_t c = 0;
+        for (uint32_t x = 0; x < ITX_SUB; x++) c += subcur[p * ITX_SUB + x];
         keys += c;
         its += (c + ITX_CHUNK - 1) / ITX_CHUNK;
     }
@@ -157,65 +137,54 @@ __global__ __launch_bounds__(1024) void k_plan(const uint32_t *__restrict__ pcou
     }
     uint32_t kb = s_k[threadIdx.x] - keys, ib = s_i[threadIdx.x] - its;   // exclusive
     for (uint32_t p = p0; p < p0 + per && p < n_part; p++) {
-        const uint32_t c = pcount[p];
-        pbase[p] = kb;
-        cursor[p] = kb;
+        const uint32_t pb = kb;
+        for (uint32_t x = 0; x < ITX_SUB; x++) {                          // sub-totals become bases
+            const uint32_t c = subcur[p * ITX_SUB + x];
+            subcur[p * ITX_SUB + x] = kb;
+            kb += c;
+        }
+        const uint32_t c = kb - pb;
         const uint32_t ni = (c + ITX_CHUNK - 1) / ITX_CHUNK;
         for (uint32_t j = 0; j < ni; j++) {
-            const uint32_t b = kb + j * ITX_CHUNK;
-            const uint32_t e = (j + 1 == ni) ? kb + c : b + ITX_CHUNK;
+            const uint32_t b = pb + j * ITX_CHUNK;
+            const uint32_t e = (j + 1 == ni) ? pb + c : b + ITX_CHUNK;
             items[ib + j] = make_uint4(p, b, e, ni == 1 ? 1u : 0u);
         }
-        kb += c;
         ib += ni;
     }
-    if (threadIdx.x == 1023) {
-        pbase[n_part] = s_k[1023];
-        *n_items = s_i[1023];
-    }
+    if (threadIdx.x == 1023) *n_items = s_i[1023];
 }
 
 // ------------------------------------------------------------------------------------------------ P
 __global__ __launch_bounds__(PB) void k_scatter(const uint32_t *__restrict__ keys0, const uint32_t *__restrict__ blk_cnt, size_t span,
-                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ keys1, uint32_t n_part)
+                                                const uint32_t *__restrict__ subcur, const uint32_t *__restrict__ offm,
+                                                uint32_t *__restrict__ keys1, uint32_t n_part)
 {
-    extern __shared__ uint32_t s_bin[];                       // [n_part] count, then reused as base
+    extern __shared__ uint32_t s_cur[];                       // [n_part] next free place of this region in each partition
+    const uint32_t sub = blockIdx.x & (ITX_SUB - 1);
+    const uint32_t *row = offm + (size_t)blockIdx.x * n_part;
+    for (uint32_t k = threadIdx.x; k < n_part; k += PB) s_cur[k] = subcur[k * ITX_SUB + sub] + row[k];
+    __syncthreads();
     const uint32_t total = blk_cnt[blockIdx.x];
     const uint32_t *in = keys0 + 2 * (size_t)blockIdx.x * span;
-    for (uint32_t k = threadIdx.x; k < n_part; k += PB) s_bin[k] = 0;
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < total; t0 += ITX_TILE) {
-        uint32_t key[ITX_TILE / PB], rank[ITX_TILE / PB];
-#pragma unroll
-        for (int j = 0; j < (int)(ITX_TILE / PB); j++) {
-            const uint32_t idx = t0 + j * PB + threadIdx.x;
-            key[j] = 0xffffffffu;
-            rank[j] = 0;
-            if (idx < total) {
-                key[j] = in[idx];
-                rank[j] = atomicAdd(&s_bin[key[j] >> (2 + ITX_LOGW)], 1u);   // ds_add_rtn: rank inside (tile, partition)
-            }
-        }
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < n_part; k += PB) {
-            const uint32_t c = s_bin[k];
-            if (c) s_bin[k] = atomicAdd(&cursor[k], c);          // reserve c places in partition k
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < (int)(ITX_TILE / PB); j++)
-            if (key[j] != 0xffffffffu) keys1[s_bin[key[j] >> (2 + ITX_LOGW)] + rank[j]] = key[j];
-        __syncthreads();
-        // clear only what was touched (bins now hold bases; untouched ones are still 0)
-#pragma unroll
-        for (int j = 0; j < (int)(ITX_TILE / PB); j++)
-            if (key[j] != 0xffffffffu) s_bin[key[j] >> (2 + ITX_LOGW)] = 0;
-        __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rounds = (total + PB - 1) / PB;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t idx = r * PB + threadIdx.x;
+        const bool has = idx < total;
+        const uint32_t key = has ? in[idx] : 0xffffffffu;
+        const uint32_t p = has ? key >> (2 + ITX_LOGW) : 0xffffffffu;
+        uint32_t len, leader;
+        const bool st = wave_run(p, has, lane, &len, &leader);
+        uint32_t base = 0;
+        if (st) base = atomicAdd(&s_cur[p], len);             // one returning LDS add per run
+        base = (uint32_t)__shfl((int32_t)base, (int)leader, 64);
+        if (has) keys1[base + (lane - leader)] = key;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ H
-__global__ __launch_bounds__(PB) void k_hist(const uint32_t *__restrict__ keys1, const uint4 *__restrict__ items,
+__global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1, const uint4 *__restrict__ items,
                                              const uint32_t *__restrict__ n_items, uint32_t *__restrict__ u32, ItxAccumLayout L,
                                              uint32_t n_slots)
 {
@@ -224,12 +193,12 @@ __global__ __launch_bounds__(PB) void k_hist(const uint32_t *__restrict__ keys1,
     for (uint32_t it = blockIdx.x; it < nI; it += gridDim.x) {
         const uint4 item = items[it];
         const uint32_t slot0 = item.x << ITX_LOGW;
-        for (uint32_t k = threadIdx.x; k < ITX_W; k += PB) {
+        for (uint32_t k = threadIdx.x; k < ITX_W; k += HB) {
             s_a[k] = 0;
             s_b[k] = 0;
         }
         __syncthreads();
-        for (uint32_t k = item.y + threadIdx.x; k < item.z; k += PB) {
+        for (uint32_t k = item.y + threadIdx.x; k < item.z; k += HB) {
             const uint32_t key = keys1[k];
             const uint32_t sl = (key >> 2) - slot0;
             const uint32_t v = 1u | ((key & 1u) << 16);
@@ -240,7 +209,7 @@ __global__ __launch_bounds__(PB) void k_hist(const uint32_t *__restrict__ keys1,
         if (lim > ITX_W) lim = ITX_W;
         if (item.w) {
             // this item owns the partition: plain read-modify-write, coalesced
-            for (uint32_t k = threadIdx.x; k < lim; k += PB) {
+            for (uint32_t k = threadIdx.x; k < lim; k += HB) {
                 const uint32_t a = s_a[k], b = s_b[k];
                 if (a) {
                     u32[L.a_all + slot0 + k] += a & 0xffffu;
@@ -252,7 +221,7 @@ __global__ __launch_bounds__(PB) void k_hist(const uint32_t *__restrict__ keys1,
                 }
             }
         } else {
-            for (uint32_t k = threadIdx.x; k < lim; k += PB) {
+            for (uint32_t k = threadIdx.x; k < lim; k += HB) {
                 const uint32_t a = s_a[k], b = s_b[k];
                 if (a) {
                     atomicAdd(&u32[L.a_all + slot0 + k], a & 0xffffu);
@@ -280,17 +249,44 @@ int itx_part_run(ItxPartWork *w, const ItxDevTable &T, const ItxRunParams &P, co
     size_t span = (n + w->max_blocks - 1) / w->max_blocks;
     span = (span + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
     const uint32_t nb = (uint32_t)((n + span - 1) / span);
-    ITX_HIP(hipMemsetAsync(w->pcount, 0, (size_t)w->n_part * 4, st));
-    int rc = itx_launch_stream(ITX_DO_EMIT, T, P, B, n, span, nb, d_hit_row, u64, u32, L, w->keys0, w->blk_cnt, st);
+    ITX_HIP(hipMemsetAsync(w->subcur, 0, (size_t)w->n_part * ITX_SUB * 4, st));
+    hipEvent_t ev[5];
+    for (int k = 0; k < 5; k++) ITX_HIP(hipEventCreate(&ev[k]));
+    ITX_HIP(hipEventRecord(ev[0], st));
+    ItxEmitPlan E = {w->subcur, w->offm, w->n_part, ITX_LOGW};
+    int rc = itx_launch_stream(ITX_DO_EMIT, T, P, B, n, span, nb, d_hit_row, u64, u32, L, w->keys0, w->blk_cnt, E, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_count, dim3(nb), dim3(PB), (size_t)w->n_part * 4, st, w->keys0, w->blk_cnt, span, w->pcount, w->n_part);
+    ITX_HIP(hipEventRecord(ev[1], st));
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, w->subcur, w->n_part, w->items, w->n_items);
     ITX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, w->pcount, w->n_part, w->pbase, w->cursor, w->items, w->n_items);
-    ITX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(PB), (size_t)w->n_part * 4, st, w->keys0, w->blk_cnt, span, w->cursor, w->keys1,
+    ITX_HIP(hipEventRecord(ev[2], st));
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(PB), (size_t)w->n_part * 4, st, w->keys0, w->blk_cnt, span, w->subcur, w->offm, w->keys1,
                        w->n_part);
     ITX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_hist, dim3(2048), dim3(PB), 0, st, w->keys1, w->items, w->n_items, u32, L, T.n_slots);
+    ITX_HIP(hipEventRecord(ev[3], st));
+    hipLaunchKernelGGL(k_hist, dim3(1024), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, L, T.n_slots);
     ITX_HIP(hipGetLastError());
+    ITX_HIP(hipEventRecord(ev[4], st));
+    for (int k = 0; k < 5; k++) w->ev.push_back(ev[k]);
     return ITX_OK;
+}
+
+void itx_part_fold_stats(ItxPartWork *w, double *ms, uint64_t *keys_last)
+{
+    for (size_t i = 0; i + 5 <= w->ev.size(); i += 5) {
+        if (hipEventSynchronize(w->ev[i + 4]) == hipSuccess)
+            for (int k = 0; k < 4; k++) {
+                float t = 0;
+                if (hipEventElapsedTime(&t, w->ev[i + k], w->ev[i + k + 1]) == hipSuccess) ms[k] += t;
+            }
+        for (int k = 0; k < 5; k++) (void)hipEventDestroy(w->ev[i + k]);
+    }
+    w->ev.clear();
+    // keys of the most recent batch = end of the last sub-cursor base + ... : read the plan's item list tail instead
+    uint32_t ni = 0;
+    if (hipMemcpy(&ni, w->n_items, 4, hipMemcpyDeviceToHost) == hipSuccess && ni > 0 && ni <= w->max_items) {
+        uint4 last;
+        if (hipMemcpy(&last, w->items + (ni - 1), sizeof last, hipMemcpyDeviceToHost) == hipSuccess) w->keys_last = last.z;
+    }
+    if (keys_last) *keys_last = w->keys_last;
 }

@@ -27,13 +27,16 @@ template <int WHAT>
 __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
                                                int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64,
                                                uint32_t *__restrict__ u32, ItxAccumLayout L, uint32_t *__restrict__ keys0,
-                                               uint32_t *__restrict__ blk_cnt)
+                                               uint32_t *__restrict__ blk_cnt, ItxEmitPlan E)
 {
     __shared__ uint4 s_win[SB / 64][2 * ITX_WIN];
     __shared__ uint32_t s_cnt[16];
     __shared__ uint32_t s_cursor;
+    extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_cursor = 0;
+    if (WHAT == ITX_DO_EMIT)
+        for (uint32_t k = threadIdx.x; k < E.n_part; k += SB) s_pc[k] = 0;
     __syncthreads();
     const uint32_t lane = lane_id();
     const uint32_t w = threadIdx.x >> 6;
@@ -310,6 +313,11 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                 base += (uint32_t)__popcll(mA[j]);
                 if (hB[j]) out[base + (uint32_t)__popcll(mB[j] & lt)] = kB[j];
                 base += (uint32_t)__popcll(mB[j]);
+                // keys per partition: one LDS add per run of equal partitions (coordinate-sorted input: long runs)
+                uint32_t len, leader;
+                const uint32_t pA = kA[j] >> (2 + E.log_w), pB = kB[j] >> (2 + E.log_w);
+                if (wave_run(pA, hA[j], lane, &len, &leader)) atomicAdd(&s_pc[pA], len);
+                if (wave_run(pB, hB[j], lane, &len, &leader)) atomicAdd(&s_pc[pB], len);
             }
         }
     }
@@ -331,12 +339,23 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
     __syncthreads();
     if (WHAT != ITX_DO_CLASSIFY && threadIdx.x < 16 && s_cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&u64[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    if (WHAT == ITX_DO_EMIT && threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cursor;
+    if (WHAT == ITX_DO_EMIT) {
+        if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cursor;
+        // reserve this region's places: ONE add per touched partition, on one of 8 sub-cursors (workgroup id mod 8 —
+        // workgroups are dealt round-robin over the 8 XCDs, so no address sees more than n_blocks/8 adds). The
+        // offsets are kept as this region's row of the offset matrix for k_scatter.
+        const uint32_t sub = blockIdx.x & (ITX_PART_SUB - 1);
+        uint32_t *row = E.offm + (size_t)blockIdx.x * E.n_part;
+        for (uint32_t k = threadIdx.x; k < E.n_part; k += SB) {
+            const uint32_t c = s_pc[k];
+            row[k] = c ? atomicAdd(&E.subcur[k * ITX_PART_SUB + sub], c) : 0u;
+        }
+    }
 }
 
 int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, size_t span,
                       unsigned n_blocks, int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, uint32_t *keys0,
-                      uint32_t *blk_cnt, hipStream_t st)
+                      uint32_t *blk_cnt, const ItxEmitPlan &E, hipStream_t st)
 {
     if (n == 0) return ITX_OK;
     const uintptr_t al = (uintptr_t)B.tid | (uintptr_t)B.pos | (uintptr_t)B.tmpend | (uintptr_t)d_hit_row;
@@ -351,16 +370,17 @@ int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, con
     const dim3 g(n_blocks), b(SB);
     switch (what) {
     case ITX_DO_CLASSIFY:
-        hipLaunchKernelGGL(k_stream<ITX_DO_CLASSIFY>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt);
+        hipLaunchKernelGGL(k_stream<ITX_DO_CLASSIFY>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt, E);
         break;
     case ITX_DO_ATOMIC_STAT:
-        hipLaunchKernelGGL(k_stream<ITX_DO_ATOMIC_STAT>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt);
+        hipLaunchKernelGGL(k_stream<ITX_DO_ATOMIC_STAT>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt, E);
         break;
     case ITX_DO_ATOMIC_LOCUS:
-        hipLaunchKernelGGL(k_stream<ITX_DO_ATOMIC_LOCUS>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt);
+        hipLaunchKernelGGL(k_stream<ITX_DO_ATOMIC_LOCUS>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt, E);
         break;
     case ITX_DO_EMIT:
-        hipLaunchKernelGGL(k_stream<ITX_DO_EMIT>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt);
+        hipLaunchKernelGGL(k_stream<ITX_DO_EMIT>, g, b, (size_t)E.n_part * 4, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0,
+                           blk_cnt, E);
         break;
     default:
         itx_set_error("internal: unknown stream action %d", what);

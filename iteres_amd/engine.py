@@ -63,7 +63,8 @@ class Result(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double), ("records", C.c_uint64), ("hits", C.c_uint64), ("reserved", C.c_uint64 * 5)]
+    _fields_ = [("kernel_ms", C.c_double), ("records", C.c_uint64), ("hits", C.c_uint64), ("stage_ms", C.c_double * 5),
+                ("submits", C.c_uint64), ("keys", C.c_uint64)]
 
 
 _lib = None
@@ -260,7 +261,8 @@ class Engine:
     def stats(self):
         s = Stats()
         _chk(load().itx_engine_get_stats(self._h, C.byref(s)), "itx_engine_get_stats")
-        return {"kernel_ms": s.kernel_ms, "records": int(s.records), "hits": int(s.hits)}
+        return {"kernel_ms": s.kernel_ms, "records": int(s.records), "hits": int(s.hits), "stage_ms": list(s.stage_ms),
+                "submits": int(s.submits), "keys": int(s.keys)}
 
     def close(self):
         if getattr(self, "_h", None):

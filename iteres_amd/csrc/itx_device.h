@@ -140,14 +140,58 @@ struct IvLds {
 // the prefix-max of the ends still exceeds qs. One hit is the answer; with several, the reference's
 // rule "last hit, in list order, whose coverage exceeds the previous hit's" (generic.c:955-959) is
 // replayed through the precomputed list-order ranks.
+// Several hits among candidates [low, hi): replay generic.c:950-970 — walk the hits in the order
+// binKeeperFind returns them (list-order rank) and keep the LAST one whose coverage exceeds its predecessor's.
+// Returns the chosen candidate or -1 (also when its coverage is below min_cov, generic.c:961-962).
 template <class ACC>
-__device__ __forceinline__ int32_t itx_pick(const ACC &A, uint32_t lo, uint32_t hi, int32_t qs, int32_t qe, uint32_t ustart, uint32_t uend,
+__device__ __noinline__ int32_t itx_pick_multi(const ACC &A, uint32_t low, uint32_t hi, int32_t qs, int32_t qe, uint32_t ustart,
+                                               uint32_t uend, float min_cov)
+{
+    int64_t best_rank = -1;
+    float tcov = 0.0f;
+    uint32_t chosen = 0;
+    for (uint32_t i = low; i < hi; i++) {
+        int32_t s, e, pm;
+        A.sep(i, s, e, pm);
+        if (clip_ov(s, e, qs, qe) <= 0) continue;
+        const uint32_t ri = A.rk(i);
+        const float ci = itx_cov(ustart, uend, s, e);
+        int64_t pr = -1;
+        float pc = 0.0f;
+        for (uint32_t k = low; k < hi; k++) {
+            if (k == i) continue;
+            int32_t s2, e2, pm2;
+            A.sep(k, s2, e2, pm2);
+            if (clip_ov(s2, e2, qs, qe) <= 0) continue;
+            const uint32_t rk = A.rk(k);
+            if (rk < ri && (int64_t)rk > pr) {
+                pr = rk;
+                pc = itx_cov(ustart, uend, s2, e2);
+            }
+        }
+        if (ci > pc && (int64_t)ri > best_rank) {
+            best_rank = ri;
+            chosen = i;
+            tcov = ci;
+        }
+    }
+    if (best_rank < 0) return -1;       // tindex == 0 in the reference (cannot happen for positive overlaps)
+    if (tcov < min_cov) return -1;
+    return (int32_t)chosen;
+}
+
+// Picks, among candidates [lo, top) — top = any bound such that every row with s < qe lies below it; rows
+// with s >= qe fail the overlap test on their own — the row the reference would pick, or -1. Hits are rows
+// with positive clipped overlap (binRange.c:216); the scan walks down while the prefix-max of the ends still
+// exceeds qs. One hit is the answer; several go through itx_pick_multi.
+template <class ACC>
+__device__ __forceinline__ int32_t itx_pick(const ACC &A, uint32_t lo, uint32_t top, int32_t qs, int32_t qe, uint32_t ustart, uint32_t uend,
                                             float min_cov)
 {
     int32_t n = 0;
-    uint32_t only = 0, low = hi;
+    uint32_t only = 0, low = top;
     int32_t os = 0, oe = 0;
-    for (uint32_t k = hi; k > lo;) {
+    for (uint32_t k = top; k > lo;) {
         --k;
         int32_t s, e, pm;
         A.sep(k, s, e, pm);
@@ -161,82 +205,48 @@ __device__ __forceinline__ int32_t itx_pick(const ACC &A, uint32_t lo, uint32_t 
         }
     }
     if (n == 0) return -1;
-    uint32_t chosen = only;
-    float tcov;
-    if (n == 1) {
-        tcov = itx_cov(ustart, uend, os, oe);
-    } else {
-        int64_t best_rank = -1;
-        tcov = 0.0f;
-        for (uint32_t i = low; i < hi; i++) {
-            int32_t s, e, pm;
-            A.sep(i, s, e, pm);
-            if (clip_ov(s, e, qs, qe) <= 0) continue;
-            const uint32_t ri = A.rk(i);
-            const float ci = itx_cov(ustart, uend, s, e);
-            int64_t pr = -1;
-            float pc = 0.0f;
-            for (uint32_t k = low; k < hi; k++) {
-                if (k == i) continue;
-                int32_t s2, e2, pm2;
-                A.sep(k, s2, e2, pm2);
-                if (clip_ov(s2, e2, qs, qe) <= 0) continue;
-                const uint32_t rk = A.rk(k);
-                if (rk < ri && (int64_t)rk > pr) {
-                    pr = rk;
-                    pc = itx_cov(ustart, uend, s2, e2);
-                }
-            }
-            if (ci > pc && (int64_t)ri > best_rank) {
-                best_rank = ri;
-                chosen = i;
-                tcov = ci;
-            }
-        }
-        if (best_rank < 0) return -1;   // tindex == 0 in the reference (cannot happen for positive overlaps)
-    }
-    if (tcov < min_cov) return -1;                                 // generic.c:961-962
-    return (int32_t)chosen;
+    if (n == 1) return itx_cov(ustart, uend, os, oe) < min_cov ? -1 : (int32_t)only;   // generic.c:961-962
+    return itx_pick_multi(A, low, top, qs, qe, ustart, uend, min_cov);
 }
 
 // Generic per-lane lookup straight from global memory (any record order). qs/qe already clipped.
 __device__ __forceinline__ int32_t itx_classify_lane(const ItxDevTable &T, uint32_t iv_lo, uint32_t bin_base, int32_t qs, int32_t qe,
                                                      uint32_t ustart, uint32_t uend, float min_cov)
 {
-    const uint2 *bl = T.bl + bin_base + ((uint32_t)qe >> T.shift);
-    uint32_t hi = bl[0].x;
-    const uint32_t top = bl[1].x;
-    if (top - hi > 8) {                                            // crowded bin: binary search for first s >= qe
-        uint32_t a = hi, b = top;
-        while (a < b) {
-            const uint32_t m = (a + b) >> 1;
-            if (T.iv[m].s < qe) a = m + 1; else b = m;
-        }
-        hi = a;
-    } else {
-        while (hi < top && T.iv[hi].s < qe) hi++;
-    }
+    // every row with s < qe starts before the end of qe's bin: that bin's upper index bounds the candidates
+    const uint32_t top = T.bl[bin_base + ((uint32_t)qe >> T.shift) + 1].x;
     IvGlobal A{T.iv, T.rank};
-    return itx_pick(A, iv_lo, hi, qs, qe, ustart, uend, min_cov);
+    return itx_pick(A, iv_lo, top, qs, qe, ustart, uend, min_cov);
 }
 
+// Wave-wide min / max over all 64 lanes with DPP row shifts and row broadcasts (VALU only; a __shfl_xor
+// butterfly lowers to six dependent ds_bpermute round trips). Every lane must be active. After the four
+// row_shr steps lane 15 of each 16-lane row holds the row's result; row_bcast:15 folds rows 0->1 and 2->3,
+// row_bcast:31 folds the lower half into the upper one; lane 63 then holds the wave's result.
+#define ITX_DPP_STEP(op, v, id, ctrl, rowmask) v = op(v, __builtin_amdgcn_update_dpp((int)(id), (int)(v), ctrl, rowmask, 0xf, false))
+__device__ __forceinline__ int32_t imin32(int32_t a, int32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ int32_t imax32(int32_t a, int32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int32_t t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
-    }
-    return v;
+    const int32_t id = 0x7fffffff;
+    ITX_DPP_STEP(imin32, v, id, 0x111, 0xf);   // row_shr:1
+    ITX_DPP_STEP(imin32, v, id, 0x112, 0xf);   // row_shr:2
+    ITX_DPP_STEP(imin32, v, id, 0x114, 0xf);   // row_shr:4
+    ITX_DPP_STEP(imin32, v, id, 0x118, 0xf);   // row_shr:8
+    ITX_DPP_STEP(imin32, v, id, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    ITX_DPP_STEP(imin32, v, id, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int32_t t = __shfl_xor(v, o, 64);
-        v = t > v ? t : v;
-    }
-    return v;
+    const int32_t id = (int32_t)0x80000000;
+    ITX_DPP_STEP(imax32, v, id, 0x111, 0xf);
+    ITX_DPP_STEP(imax32, v, id, 0x112, 0xf);
+    ITX_DPP_STEP(imax32, v, id, 0x114, 0xf);
+    ITX_DPP_STEP(imax32, v, id, 0x118, 0xf);
+    ITX_DPP_STEP(imax32, v, id, 0x142, 0xa);
+    ITX_DPP_STEP(imax32, v, id, 0x143, 0xc);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Runs of equal values over the lanes of a wave (every lane must call). Returns whether this lane starts a

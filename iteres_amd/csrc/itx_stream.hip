@@ -10,10 +10,13 @@
 //   * ONE coalesced load brings the slice of the binned index covering the tile into registers (lane j holds
 //     bin j); the candidate window [lo_w, hi_w) of table rows comes out of it with two lane reads,
 //   * ONE coalesced load stages the window's rows (32 B each, <= 128 rows) into the wave's LDS window,
-//   * every record then finds its upper bound with two ds_bpermute reads of the index slice and a step or
-//     two in LDS, and replays the reference's best-hit rule over LDS.
+//   * every record takes the top of its bin from the index slice (one ds_bpermute) and walks down the LDS
+//     window while the prefix-max of the row ends still exceeds its start; the four records of a lane advance
+//     in lockstep, one ds_read_b128 each per step.
 // Tiles that do not fit this picture (mixed chromosomes, > 64 bins or > 128 rows: unsorted or very sparse
 // input) take the per-lane global-memory lookup — slower, same results.
+// The tile body is written predicated (selects, no early exits): the kernel is bound by instruction issue,
+// and nested divergent branches cost more exec-mask bookkeeping than the arithmetic they skip.
 // No MFMA: the path is integer compares and one f32 ratio; the roofline that bounds it is HBM.
 #include "itx_device.h"
 
@@ -21,7 +24,67 @@
 #define RPL 4
 #define WTILE (64 * RPL)
 
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// generic.c:748-922 for one record, predicated. tr = first 16 bytes of the record's ItxTidRec.
+struct Derived {
+    uint32_t cntbits;      // bit k: cnt[k] += 1 for k in 0..7 (generic.c:1048-1055); cnt[11] == cnt[7] without -R
+    uint32_t start, end;
+    bool ok, uniq;
+};
+__device__ __forceinline__ Derived derive_pred(const ItxRunParams &P, const ItxRaw &r, const uint4 &tr, int32_t isz, int32_t mpos)
+{
+    Derived d;
+    const uint32_t fl = r.fl;
+    const bool paired = fl & F5_PAIRED, unmap = fl & F5_UNMAP, munmap = fl & F5_MUNMAP, rev = fl & F5_REVERSE, read1 = fl & F5_READ1;
+    const bool treat = P.treat != 0;
+    const bool end1 = !paired || read1 || treat;                                   // generic.c:748-759
+    const bool mapped = !unmap;                                                    // generic.c:764
+    const uint32_t cend = tr.y - 1u;                                               // generic.c:796
+    const bool chrom_ok = mapped && (int32_t)tr.x >= 0 && cend != 1u;              // generic.c:781-801
+    const bool se = treat || !paired || munmap;                                    // generic.c:815,836-837,885
+    const uint32_t aisz = isz < 0 ? 0u - (uint32_t)isz : (uint32_t)isz;
+    const bool pe_ok = read1 && aisz <= P.isize_max && isz != 0;                   // generic.c:838-840,858-860
+    const bool se_ok = treat || !paired || P.discard == 0;                         // generic.c:862-863
+    d.ok = chrom_ok && (se ? se_ok : pe_ok);
+    d.uniq = r.mapq >= P.mapq_min;
+    // generic.c:819-833
+    uint32_t s_se = (uint32_t)r.pos;
+    uint32_t e_se = umin32(cend, (uint32_t)r.tmpend);
+    if (P.extension) {                                                             // wave-uniform
+        const uint32_t e_plus = umin32(s_se + P.extension, cend);
+        const uint32_t s_minus = e_se < P.extension ? 0u : e_se - P.extension;
+        s_se = rev ? s_minus : s_se;
+        e_se = rev ? e_se : e_plus;
+    }
+    // generic.c:845-855
+    const bool fwd = isz > 0;
+    const uint32_t s_pe = fwd ? (uint32_t)r.pos : (uint32_t)mpos;
+    const uint32_t e_pe = umin32(cend, fwd ? s_pe + (uint32_t)isz : s_pe - (uint32_t)isz);
+    d.start = se ? s_se : s_pe;
+    d.end = se ? e_se : e_pe;
+    d.cntbits = (end1 ? 1u : 2u) | (mapped ? (end1 ? 4u : 8u) : 0u) | (chrom_ok ? (end1 ? 16u : 32u) : 0u) | (d.ok ? 64u : 0u) |
+                (d.ok && d.uniq ? 128u : 0u);
+    return d;
+}
+
+// bit k of an 8-bit value -> 1 in nibble k
+__device__ __forceinline__ uint32_t spread8(uint32_t x)
+{
+    uint32_t t = (x | (x << 12)) & 0x000f000fu;
+    t = (t | (t << 3) | (t << 6) | (t << 9)) & 0x11111111u;
+    return t;
+}
+
+__device__ __forceinline__ uint32_t uadd32(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    ITX_DPP_STEP(uadd32, v, 0, 0x111, 0xf);
+    ITX_DPP_STEP(uadd32, v, 0, 0x112, 0xf);
+    ITX_DPP_STEP(uadd32, v, 0, 0x114, 0xf);
+    ITX_DPP_STEP(uadd32, v, 0, 0x118, 0xf);
+    ITX_DPP_STEP(uadd32, v, 0, 0x142, 0xa);
+    ITX_DPP_STEP(uadd32, v, 0, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 template <int WHAT>
 __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
@@ -30,15 +93,17 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                                                uint32_t *__restrict__ blk_cnt, ItxEmitPlan E)
 {
     __shared__ uint4 s_win[SB / 64][2 * ITX_WIN];
+    __shared__ uint32_t s_lut[256];
     __shared__ uint32_t s_cnt[16];
     __shared__ uint32_t s_cursor;
     extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
+    s_lut[threadIdx.x] = spread8(threadIdx.x);
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_cursor = 0;
     if (WHAT == ITX_DO_EMIT)
         for (uint32_t k = threadIdx.x; k < E.n_part; k += SB) s_pc[k] = 0;
     __syncthreads();
-    const uint32_t lane = lane_id();
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     uint4 *win = s_win[w];
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -46,18 +111,28 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
     size_t end = begin + span;
     if (end > n) end = n;
     uint32_t *out = keys0 ? keys0 + 2 * begin : nullptr;
+    const bool have_pe = B.isize != nullptr;
 
     // wave-uniform cache of the current reference's ItxTidRec
     int32_t cur_tid = -0x7fffffff;
     uint4 cur0 = make_uint4(0xffffffffu, 0, 0, 0);
     uint32_t cur_bb = 0;
-    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0, c9 = 0, c10 = 0;
+    // per-lane counters (generic.c:1048-1060), reduced over the wave once at the end
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_hit = 0, acc_hitu = 0;
+#ifdef ITX_ABLATE
+    uint32_t sink = 0;      // timing-only builds: stop the tile early, keep what was computed alive
+#define ITX_ABLATE_AT(k, expr) if (ITX_ABLATE == (k)) { sink += (expr); continue; }
+#else
+#define ITX_ABLATE_AT(k, expr)
+#endif
 
     for (size_t tb = begin + (size_t)w * WTILE; tb < end; tb += (size_t)(SB / 64) * WTILE) {
         const size_t r0 = tb + (size_t)lane * RPL;
+        const bool full = tb + WTILE <= end;                                    // wave-uniform
         ItxRaw raw[RPL];
         bool ex[RPL];
-        if (tb + WTILE <= end) {
+        int32_t isz[RPL] = {0, 0, 0, 0}, mps[RPL] = {0, 0, 0, 0};
+        if (full) {
             const int4 t4 = *reinterpret_cast<const int4 *>(B.tid + r0);
             const int4 p4 = *reinterpret_cast<const int4 *>(B.pos + r0);
             const int4 e4 = *reinterpret_cast<const int4 *>(B.tmpend + r0);
@@ -69,20 +144,33 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
             raw[3] = {t4.w, p4.w, e4.w, mq >> 24, f4 >> 24};
 #pragma unroll
             for (int j = 0; j < RPL; j++) ex[j] = true;
+            if (have_pe && __ballot(f4 & 0x01010101u)) {                        // some record of the tile is paired
+                const int4 i4 = *reinterpret_cast<const int4 *>(B.isize + r0);
+                const int4 m4 = *reinterpret_cast<const int4 *>(B.mpos + r0);
+                isz[0] = i4.x; isz[1] = i4.y; isz[2] = i4.z; isz[3] = i4.w;
+                mps[0] = m4.x; mps[1] = m4.y; mps[2] = m4.z; mps[3] = m4.w;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 ex[j] = r0 + j < end;
                 raw[j] = {0, 0, 0, 0, 0};
-                if (ex[j]) raw[j] = {B.tid[r0 + j], B.pos[r0 + j], B.tmpend[r0 + j], B.mapq[r0 + j], B.flag5[r0 + j]};
+                if (ex[j]) {
+                    raw[j] = {B.tid[r0 + j], B.pos[r0 + j], B.tmpend[r0 + j], B.mapq[r0 + j], B.flag5[r0 + j]};
+                    if (have_pe) {
+                        isz[j] = B.isize[r0 + j];
+                        mps[j] = B.mpos[r0 + j];
+                    }
+                }
             }
         }
+        ITX_ABLATE_AT(1, raw[0].tid + raw[1].pos + raw[2].tmpend + raw[3].mapq + raw[3].fl)
         // ---- per-reference record: wave-uniform when every record of the tile shares one tid
         bool same = true;
 #pragma unroll
         for (int j = 0; j < RPL; j++) same = same && (!ex[j] || raw[j].tid == cur_tid);
         if (__ballot(!same)) {
-            const int32_t t0 = __shfl(raw[0].tid, 0, 64);          // record tb exists (tb < end)
+            const int32_t t0 = __builtin_amdgcn_readfirstlane(raw[0].tid);     // record tb exists (tb < end)
             cur_tid = t0;
             if (t0 >= 0 && t0 < P.n_tid) {
                 cur0 = *reinterpret_cast<const uint4 *>(&P.tidrec[t0]);
@@ -98,7 +186,7 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
         const bool uniform = __ballot(!same) == 0ull;
 
         // ---- derive
-        ItxDerived d[RPL];
+        Derived d[RPL];
         uint4 tr[RPL];
         uint32_t bb[RPL];
         int32_t qs[RPL], qe[RPL];
@@ -108,7 +196,10 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
         for (int j = 0; j < RPL; j++) {
             tr[j] = cur0;
             bb[j] = cur_bb;
-            if (!uniform) {
+        }
+        if (!uniform) {                                                         // mixed references in one tile: rare
+#pragma unroll
+            for (int j = 0; j < RPL; j++) {
                 const int32_t t = raw[j].tid;
                 if (ex[j] && t >= 0 && t < P.n_tid) {
                     tr[j] = *reinterpret_cast<const uint4 *>(&P.tidrec[t]);
@@ -117,25 +208,27 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                     tr[j] = make_uint4(0xffffffffu, 0, 0, 0);
                 }
             }
-            d[j].cntbits = 0;
-            d[j].ok = false;
-            d[j].uniq = false;
-            d[j].start = d[j].end = 0;
-            if (ex[j]) d[j] = itx_derive(P, B, raw[j], tr[j], r0 + j);
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            d[j] = derive_pred(P, raw[j], tr[j], isz[j], mps[j]);
+            if (!ex[j]) {
+                d[j].cntbits = 0;
+                d[j].ok = false;
+            }
             // binKeeperFind(bk, int start, int end) with its clipping (binRange.c:204-206)
-            qs[j] = (int32_t)d[j].start;
-            qe[j] = (int32_t)d[j].end;
-            if (qs[j] < 0) qs[j] = 0;
-            if (qe[j] > (int32_t)tr[j].y) qe[j] = (int32_t)tr[j].y;
+            qs[j] = imax32((int32_t)d[j].start, 0);
+            qe[j] = imin32((int32_t)d[j].end, (int32_t)tr[j].y);
             q[j] = d[j].ok && qs[j] < qe[j] && tr[j].z < tr[j].w;
             anyq = anyq || q[j];
         }
+        ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + (uint32_t)qs[2] + (uint32_t)qe[3] + d[0].cntbits + d[1].cntbits + d[2].cntbits + d[3].cntbits)
 
         // ---- classify
-        int32_t hit[RPL];
+        int32_t hit[RPL] = {-1, -1, -1, -1};
         ItxIv rec[RPL];
 #pragma unroll
-        for (int j = 0; j < RPL; j++) hit[j] = -1;
+        for (int j = 0; j < RPL; j++) rec[j] = ItxIv{0, 0, 0, 0, 0, 0, 0, 0};
         if (__ballot(anyq)) {
             bool fast = uniform;
             uint32_t lo_w = 0, wn = 0, bin_lo = 0;
@@ -144,10 +237,8 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                 int32_t mn = 0x7fffffff, mx = 0;
 #pragma unroll
                 for (int j = 0; j < RPL; j++) {
-                    if (q[j]) {
-                        mn = qs[j] < mn ? qs[j] : mn;
-                        mx = qe[j] > mx ? qe[j] : mx;
-                    }
+                    mn = q[j] ? imin32(qs[j], mn) : mn;
+                    mx = q[j] ? imax32(qe[j], mx) : mx;
                 }
                 mn = wave_min_i32(mn);
                 mx = wave_max_i32(mx);
@@ -156,8 +247,8 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                 fast = nb <= 64;
                 if (fast) {
                     if (lane < nb) bs = T.bl[cur_bb + bin_lo + lane];
-                    lo_w = (uint32_t)__shfl((int32_t)bs.y, 0, 64);
-                    const uint32_t hi_w = (uint32_t)__shfl((int32_t)bs.x, (int)(nb - 1), 64);
+                    lo_w = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)bs.y);
+                    const uint32_t hi_w = (uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, (int)(nb - 1));
                     wn = hi_w > lo_w ? hi_w - lo_w : 0u;
                     fast = wn <= ITX_WIN;
                 }
@@ -169,35 +260,69 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    IvLds A{win, T.rank, lo_w};
+                    ITX_ABLATE_AT(3, win[2 * (lane % wn)].x + wn)
+                    // Candidates of a record: window rows below the top of qe's bin (one lane read of the index
+                    // slice); rows starting at or after qe fail the overlap test by themselves. The four records of a
+                    // lane walk down in lockstep while the prefix-max of the ends still exceeds qs
+                    // (binRange.c:209-225 without the bin lists).
+                    uint32_t kk[RPL], top[RPL], only[RPL], low[RPL];
+                    int32_t nh[RPL], os[RPL], oe[RPL];
+                    bool act[RPL];
+                    bool any = false;
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        // upper bound: rows with s < qe end inside bin(qe); two lane reads of the index slice
-                        const uint32_t b = q[j] ? ((uint32_t)qe[j] >> T.shift) - bin_lo : 0u;
-                        uint32_t h0 = (uint32_t)__shfl((int32_t)bs.x, (int)b, 64);
-                        uint32_t h1 = (uint32_t)__shfl((int32_t)bs.x, (int)b + 1, 64);
-                        if (q[j]) {
-                            h0 = h0 > lo_w ? h0 - lo_w : 0u;
-                            h1 = h1 > lo_w ? h1 - lo_w : 0u;
-                            uint32_t hi = h0;
-                            if (h1 - h0 > 8) {
-                                uint32_t a = h0, bnd = h1;
-                                while (a < bnd) {
-                                    const uint32_t m = (a + bnd) >> 1;
-                                    if (A.s(m) < qe[j]) a = m + 1; else bnd = m;
-                                }
-                                hi = a;
-                            } else {
-                                while (hi < h1 && A.s(hi) < qe[j]) hi++;
-                            }
-                            const int32_t k = itx_pick(A, 0u, hi, qs[j], qe[j], d[j].start, d[j].end, P.min_cov);
-                            if (k >= 0) {
-                                hit[j] = (int32_t)lo_w + k;
-                                const uint4 v0 = win[2 * k], v1 = win[2 * k + 1];
-                                rec[j].s = (int32_t)v0.x; rec[j].e = (int32_t)v0.y; rec[j].pmax_e = (int32_t)v0.z; rec[j].cs = v0.w;
-                                rec[j].jcap = v1.x; rec[j].covslot = v1.y; rec[j].zslot = v1.z; rec[j].unit = v1.w;
-                            }
+                        const uint32_t b = q[j] ? ((uint32_t)qe[j] >> T.shift) - bin_lo + 1u : 0u;
+                        uint32_t h1 = (uint32_t)__shfl((int32_t)bs.x, (int)b, 64);
+                        h1 = h1 > lo_w ? h1 - lo_w : 0u;
+                        top[j] = kk[j] = low[j] = h1;
+                        act[j] = q[j] && h1 > 0;
+                        nh[j] = 0;
+                        only[j] = 0;
+                        os[j] = oe[j] = 0;
+                        any = any || act[j];
+                    }
+                    while (any) {
+                        uint4 v[RPL];
+#pragma unroll
+                        for (int j = 0; j < RPL; j++) {
+                            kk[j] = act[j] ? kk[j] - 1 : 0u;
+                            v[j] = win[2 * kk[j]];
                         }
+                        any = false;
+#pragma unroll
+                        for (int j = 0; j < RPL; j++) {
+                            const bool alive = act[j] && (int32_t)v[j].z > qs[j];
+                            const bool ovl = alive && clip_ov((int32_t)v[j].x, (int32_t)v[j].y, qs[j], qe[j]) > 0;
+                            nh[j] += ovl ? 1 : 0;
+                            only[j] = ovl ? kk[j] : only[j];
+                            os[j] = ovl ? (int32_t)v[j].x : os[j];
+                            oe[j] = ovl ? (int32_t)v[j].y : oe[j];
+                            low[j] = alive ? kk[j] : low[j];
+                            act[j] = alive && kk[j] > 0;
+                            any = any || act[j];
+                        }
+                    }
+                    bool multi = false;
+#pragma unroll
+                    for (int j = 0; j < RPL; j++) {
+                        const float c = itx_cov(d[j].start, d[j].end, os[j], oe[j]);
+                        const bool one = nh[j] == 1 && !(c < P.min_cov);                // generic.c:961-962
+                        hit[j] = one ? (int32_t)only[j] : -1;
+                        multi = multi || nh[j] > 1;
+                    }
+                    if (__ballot(multi)) {                                              // several hits: rare
+                        IvLds A{win, T.rank, lo_w};
+#pragma unroll
+                        for (int j = 0; j < RPL; j++)
+                            if (nh[j] > 1) hit[j] = itx_pick_multi(A, low[j], top[j], qs[j], qe[j], d[j].start, d[j].end, P.min_cov);
+                    }
+#pragma unroll
+                    for (int j = 0; j < RPL; j++) {
+                        const uint32_t k = hit[j] >= 0 ? (uint32_t)hit[j] : 0u;
+                        const uint4 v0 = win[2 * k], v1 = win[2 * k + 1];
+                        rec[j].s = (int32_t)v0.x; rec[j].e = (int32_t)v0.y; rec[j].pmax_e = (int32_t)v0.z; rec[j].cs = v0.w;
+                        rec[j].jcap = v1.x; rec[j].covslot = v1.y; rec[j].zslot = v1.z; rec[j].unit = v1.w;
+                        hit[j] = hit[j] >= 0 ? hit[j] + (int32_t)lo_w : -1;
                     }
                     __builtin_amdgcn_wave_barrier();                                    // the window is rewritten next tile
                 }
@@ -211,29 +336,27 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                 }
             }
         }
+        ITX_ABLATE_AT(4, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]))
 
-        // ---- cnt[] (generic.c:1048-1060): wave popcounts into scalar accumulators
+        // ---- cnt[] (generic.c:1048-1060): nibble-wise per-lane sums of the four records' bits
+        {
+            const uint32_t n4 = s_lut[d[0].cntbits] + s_lut[d[1].cntbits] + s_lut[d[2].cntbits] + s_lut[d[3].cntbits];
 #pragma unroll
-        for (int j = 0; j < RPL; j++) {
-            const uint32_t cb = d[j].cntbits;
-            c0 += (uint32_t)__popcll(__ballot(cb & 1u));
-            c1 += (uint32_t)__popcll(__ballot(cb & 2u));
-            c2 += (uint32_t)__popcll(__ballot(cb & 4u));
-            c3 += (uint32_t)__popcll(__ballot(cb & 8u));
-            c4 += (uint32_t)__popcll(__ballot(cb & 16u));
-            c5 += (uint32_t)__popcll(__ballot(cb & 32u));
-            c6 += (uint32_t)__popcll(__ballot(cb & 64u));
-            c7 += (uint32_t)__popcll(__ballot(cb & 128u));
-            c9 += (uint32_t)__popcll(__ballot(hit[j] >= 0));                      // generic.c:1030-1032
-            c10 += (uint32_t)__popcll(__ballot(hit[j] >= 0 && d[j].uniq));
+            for (int k = 0; k < 8; k++) acc[k] += (n4 >> (4 * k)) & 0xfu;
+#pragma unroll
+            for (int j = 0; j < RPL; j++) {
+                acc_hit += hit[j] >= 0 ? 1u : 0u;                                       // generic.c:1030-1032
+                acc_hitu += (hit[j] >= 0 && d[j].uniq) ? 1u : 0u;
+            }
         }
+        ITX_ABLATE_AT(5, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]) + acc[0] + acc_hit)
 
         // ---- chosen rows back to the caller (row ids as passed to itx_table_create)
         if (d_hit_row) {
             int32_t h[RPL];
 #pragma unroll
             for (int j = 0; j < RPL; j++) h[j] = hit[j] >= 0 ? T.orig[hit[j]] : -1;
-            if (tb + WTILE <= end) {
+            if (full) {
                 *reinterpret_cast<int4 *>(d_hit_row + r0) = make_int4(h[0], h[1], h[2], h[3]);
             } else {
 #pragma unroll
@@ -266,17 +389,8 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
             // slCount(ss->sl) per locus (generic.c:662-666,1725): one atomic per run of equal rows in the wave
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
-                const int32_t h = hit[j];
-                const int32_t hp = __shfl_up(h, 1, 64);
-                const bool has = h >= 0;
-                const bool st = has && (lane == 0 || hp != h);
-                const unsigned long long m_st = __ballot(st), m_has = __ballot(has);
-                if (st) {
-                    // run = consecutive lanes with the same row: ends at the next run start or the next lane without a hit
-                    const unsigned long long stop = (m_st | ~m_has) & ~((lt << 1) | 1ull);
-                    const uint32_t e = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
-                    atomicAdd(&u32[L.locus + (uint32_t)h], e - lane);
-                }
+                uint32_t len, leader;
+                if (wave_run((uint32_t)hit[j], hit[j] >= 0, lane, &len, &leader)) atomicAdd(&u32[L.locus + (uint32_t)hit[j]], len);
             }
         } else if (WHAT == ITX_DO_EMIT) {
             uint32_t kA[RPL], kB[RPL];
@@ -285,56 +399,58 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
             unsigned long long mA[RPL], mB[RPL];
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
+                uint32_t first;
+                const uint32_t nc = itx_cov_range(rec[j], d[j].start, d[j].end, &first);
+                const uint32_t u = d[j].uniq ? 1u : 0u;
                 hA[j] = hit[j] >= 0;
-                hB[j] = false;
-                kA[j] = kB[j] = 0;
-                if (hA[j]) {
-                    uint32_t first;
-                    const uint32_t nc = itx_cov_range(rec[j], d[j].start, d[j].end, &first);
-                    const uint32_t u = d[j].uniq ? 1u : 0u;
-                    if (nc) {
-                        kA[j] = (first << 2) | u;
-                        kB[j] = ((first + nc) << 2) | 2u | u;
-                        hB[j] = true;
-                    } else {
-                        kA[j] = (rec[j].zslot << 2) | u;
-                    }
-                }
+                hB[j] = hA[j] && nc != 0;
+                kA[j] = ((hB[j] ? first : rec[j].zslot) << 2) | u;                     // no coverage: one start in the unit's extra slot
+                kB[j] = ((first + nc) << 2) | 2u | u;
                 mA[j] = __ballot(hA[j]);
                 mB[j] = __ballot(hB[j]);
                 total += (uint32_t)__popcll(mA[j]) + (uint32_t)__popcll(mB[j]);
             }
             uint32_t base = 0;
             if (lane == 0 && total) base = atomicAdd(&s_cursor, total);          // the workgroup's region cursor (LDS)
-            base = (uint32_t)__shfl((int32_t)base, 0, 64);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base);
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 if (hA[j]) out[base + (uint32_t)__popcll(mA[j] & lt)] = kA[j];
                 base += (uint32_t)__popcll(mA[j]);
                 if (hB[j]) out[base + (uint32_t)__popcll(mB[j] & lt)] = kB[j];
                 base += (uint32_t)__popcll(mB[j]);
-                // keys per partition: one LDS add per run of equal partitions (coordinate-sorted input: long runs)
+                // keys per partition: one LDS add per run of equal start-key partitions (coordinate-sorted input: long
+                // runs); an end key almost always falls in its start key's partition and rides along
                 uint32_t len, leader;
                 const uint32_t pA = kA[j] >> (2 + E.log_w), pB = kB[j] >> (2 + E.log_w);
-                if (wave_run(pA, hA[j], lane, &len, &leader)) atomicAdd(&s_pc[pA], len);
-                if (wave_run(pB, hB[j], lane, &len, &leader)) atomicAdd(&s_pc[pB], len);
+                const bool st = wave_run(pA, hA[j], lane, &len, &leader);
+                const bool b_same = hB[j] && pB == pA;
+                const unsigned long long m_same = __ballot(b_same);
+                if (st) {
+                    const unsigned long long run = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
+                    atomicAdd(&s_pc[pA], len + (uint32_t)__popcll(m_same & run));
+                }
+                if (hB[j] && !b_same) atomicAdd(&s_pc[pB], 1u);
             }
         }
     }
-    if (WHAT != ITX_DO_CLASSIFY && lane == 0) {          // classify-only launches leave every accumulator alone
-        if (c0) atomicAdd(&s_cnt[0], c0);
-        if (c1) atomicAdd(&s_cnt[1], c1);
-        if (c2) atomicAdd(&s_cnt[2], c2);
-        if (c3) atomicAdd(&s_cnt[3], c3);
-        if (c4) atomicAdd(&s_cnt[4], c4);
-        if (c5) atomicAdd(&s_cnt[5], c5);
-        if (c6) atomicAdd(&s_cnt[6], c6);
-        if (c7) {
-            atomicAdd(&s_cnt[7], c7);
-            atomicAdd(&s_cnt[11], c7);                    // reads_nonredundant_unique == reads_mapped_unique without -R
+#ifdef ITX_ABLATE
+    if (sink == 0x7fffff01u) s_cnt[12] = sink;
+#endif
+    if (WHAT != ITX_DO_CLASSIFY) {                        // classify-only launches leave every accumulator alone
+        uint32_t tot[10];
+#pragma unroll
+        for (int k = 0; k < 8; k++) tot[k] = wave_sum_u32(acc[k]);
+        tot[8] = wave_sum_u32(acc_hit);
+        tot[9] = wave_sum_u32(acc_hitu);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (tot[k]) atomicAdd(&s_cnt[k], tot[k]);
+            if (tot[7]) atomicAdd(&s_cnt[11], tot[7]);    // reads_nonredundant_unique == reads_mapped_unique without -R
+            if (tot[8]) atomicAdd(&s_cnt[9], tot[8]);
+            if (tot[9]) atomicAdd(&s_cnt[10], tot[9]);
         }
-        if (c9) atomicAdd(&s_cnt[9], c9);
-        if (c10) atomicAdd(&s_cnt[10], c10);
     }
     __syncthreads();
     if (WHAT != ITX_DO_CLASSIFY && threadIdx.x < 16 && s_cnt[threadIdx.x])
@@ -358,9 +474,9 @@ int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, con
                       uint32_t *blk_cnt, const ItxEmitPlan &E, hipStream_t st)
 {
     if (n == 0) return ITX_OK;
-    const uintptr_t al = (uintptr_t)B.tid | (uintptr_t)B.pos | (uintptr_t)B.tmpend | (uintptr_t)d_hit_row;
+    const uintptr_t al = (uintptr_t)B.tid | (uintptr_t)B.pos | (uintptr_t)B.tmpend | (uintptr_t)d_hit_row | (uintptr_t)B.mpos | (uintptr_t)B.isize;
     if ((al & 15u) || (((uintptr_t)B.mapq | (uintptr_t)B.flag5) & 3u)) {
-        itx_set_error("record arrays must be 16-byte aligned (tid/pos/tmpend/hit_row) and 4-byte aligned (mapq/flag5)");
+        itx_set_error("record arrays must be 16-byte aligned (tid/pos/tmpend/mpos/isize/hit_row) and 4-byte aligned (mapq/flag5)");
         return ITX_E_ARG;
     }
     if (span % ITX_STREAM_TILE) {

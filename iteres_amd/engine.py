@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libiteres_amd.so")
+LIB_PATH = os.environ.get("ITX_LIB", os.path.join(HERE, "libiteres_amd.so"))   # ITX_LIB: timing-only experiment builds
 
 MODE_STAT, MODE_FILTER = 0, 1
 ACCUM_DEFAULT, ACCUM_ATOMIC, ACCUM_PARTITION = 0, 1, 2

@@ -9,20 +9,21 @@
 // One interval of the device table, 32 bytes (two dwordx4 loads). Intervals of a chromosome are
 // contiguous and sorted by (start, file order).
 struct __attribute__((aligned(16))) ItxIv {
+    // first 16 bytes: all the overlap scan reads
     int32_t  s, e;        // genomic [s, e)
     int32_t  pmax_e;      // max e over this chromosome's intervals [first .. this]: scan-stop bound
+    uint32_t rank;        // position in binKeeperFind's list order within the chromosome (binRange.c:209-225)
+    // second 16 bytes: read once, for the chosen row
     uint32_t cs;          // consensus_start as the reference parses it (generic.c:1596-1600)
     uint32_t jcap;        // min(consensus_end, repeat length): first consensus index NOT incremented
     uint32_t covslot;     // first slot of the interval's unit inside the slot space (rep_len+1 slots per unit)
     uint32_t zslot;       // covslot + rep_len: the unit's extra slot (never part of the coverage output)
-    uint32_t unit;        // the row's (repName, repFamily, repClass) unit
 };
 static_assert(sizeof(ItxIv) == 32, "ItxIv must be 32 bytes");
 
 // Device view of the table (passed to kernels by value).
 struct ItxDevTable {
     const ItxIv    *iv;         // [n_rows]
-    const uint32_t *rank;       // [n_rows] position in binKeeperFind's list order within the chromosome
     const int32_t  *orig;       // [n_rows] sorted index -> caller's row index
     const uint2    *bl;         // binned index, one slice per chromosome (ItxTidRec.bin_base), per bin b of 2^shift bp:
                                 //   .x = first index with s >= (b << shift)          (upper bound of "s < x" queries)

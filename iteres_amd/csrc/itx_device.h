@@ -113,26 +113,23 @@ __device__ __forceinline__ int32_t clip_ov(int32_t s, int32_t e, int32_t qs, int
 // wave's LDS window (coordinate-sorted input, the fast path).
 struct IvGlobal {
     const ItxIv *iv;
-    const uint32_t *rank;
     __device__ __forceinline__ int32_t s(uint32_t k) const { return iv[k].s; }
     __device__ __forceinline__ void sep(uint32_t k, int32_t &s_, int32_t &e_, int32_t &pm) const
     {
         const uint4 v = *reinterpret_cast<const uint4 *>(&iv[k]);
         s_ = (int32_t)v.x; e_ = (int32_t)v.y; pm = (int32_t)v.z;
     }
-    __device__ __forceinline__ uint32_t rk(uint32_t k) const { return rank[k]; }
+    __device__ __forceinline__ uint32_t rk(uint32_t k) const { return iv[k].rank; }
 };
 struct IvLds {
     const uint4 *w;            // entry j at w[2j], w[2j+1]
-    const uint32_t *rank;      // global ranks, indexed base + j
-    uint32_t base;
     __device__ __forceinline__ int32_t s(uint32_t j) const { return (int32_t)w[2 * j].x; }
     __device__ __forceinline__ void sep(uint32_t j, int32_t &s_, int32_t &e_, int32_t &pm) const
     {
         const uint4 v = w[2 * j];
         s_ = (int32_t)v.x; e_ = (int32_t)v.y; pm = (int32_t)v.z;
     }
-    __device__ __forceinline__ uint32_t rk(uint32_t j) const { return rank[base + j]; }
+    __device__ __forceinline__ uint32_t rk(uint32_t j) const { return w[2 * j].w; }
 };
 
 // Picks, among candidates [lo, hi) (hi = first candidate with s >= qe), the row the reference would
@@ -215,7 +212,7 @@ __device__ __forceinline__ int32_t itx_classify_lane(const ItxDevTable &T, uint3
 {
     // every row with s < qe starts before the end of qe's bin: that bin's upper index bounds the candidates
     const uint32_t top = T.bl[bin_base + ((uint32_t)qe >> T.shift) + 1].x;
-    IvGlobal A{T.iv, T.rank};
+    IvGlobal A{T.iv};
     return itx_pick(A, iv_lo, top, qs, qe, ustart, uend, min_cov);
 }
 

@@ -265,8 +265,10 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                     // slice); rows starting at or after qe fail the overlap test by themselves. The four records of a
                     // lane walk down in lockstep while the prefix-max of the ends still exceeds qs
                     // (binRange.c:209-225 without the bin lists).
-                    uint32_t kk[RPL], top[RPL], only[RPL], low[RPL];
-                    int32_t nh[RPL], os[RPL], oe[RPL];
+                    uint32_t kk[RPL], top[RPL], low[RPL];
+                    uint32_t h_k[RPL], h_ov[RPL], h_rk[RPL];      // the hit found last (lowest row so far)
+                    uint32_t g_k[RPL], g_ov[RPL], g_rk[RPL];      // the hit found before it
+                    int32_t nh[RPL];
                     bool act[RPL];
                     bool any = false;
 #pragma unroll
@@ -277,8 +279,7 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                         top[j] = kk[j] = low[j] = h1;
                         act[j] = q[j] && h1 > 0;
                         nh[j] = 0;
-                        only[j] = 0;
-                        os[j] = oe[j] = 0;
+                        h_k[j] = h_ov[j] = h_rk[j] = g_k[j] = g_ov[j] = g_rk[j] = 0;
                         any = any || act[j];
                     }
                     while (any) {
@@ -286,42 +287,62 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
                             kk[j] = act[j] ? kk[j] - 1 : 0u;
-                            v[j] = win[2 * kk[j]];
+                            v[j] = win[2 * kk[j]];                                      // s, e, pmax_e, rank
                         }
                         any = false;
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
                             const bool alive = act[j] && (int32_t)v[j].z > qs[j];
-                            const bool ovl = alive && clip_ov((int32_t)v[j].x, (int32_t)v[j].y, qs[j], qe[j]) > 0;
+                            const int32_t ov = clip_ov((int32_t)v[j].x, (int32_t)v[j].y, qs[j], qe[j]);
+                            const bool ovl = alive && ov > 0;
                             nh[j] += ovl ? 1 : 0;
-                            only[j] = ovl ? kk[j] : only[j];
-                            os[j] = ovl ? (int32_t)v[j].x : os[j];
-                            oe[j] = ovl ? (int32_t)v[j].y : oe[j];
+                            g_k[j] = ovl ? h_k[j] : g_k[j];
+                            g_ov[j] = ovl ? h_ov[j] : g_ov[j];
+                            g_rk[j] = ovl ? h_rk[j] : g_rk[j];
+                            h_k[j] = ovl ? kk[j] : h_k[j];
+                            h_ov[j] = ovl ? (uint32_t)ov : h_ov[j];
+                            h_rk[j] = ovl ? v[j].w : h_rk[j];
                             low[j] = alive ? kk[j] : low[j];
                             act[j] = alive && kk[j] > 0;
                             any = any || act[j];
                         }
                     }
+                    // Best hit (generic.c:950-970): in binKeeperFind's list order, the LAST hit whose coverage exceeds the
+                    // previous hit's. All hits of a record share the denominator (end - start) and, for overlaps below
+                    // 2^23, distinct integer overlaps give distinct f32 quotients — so with two hits the pick is an integer
+                    // comparison on (rank, overlap); three or more hits (or giant fragments) replay the rule in full.
                     bool multi = false;
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        const float c = itx_cov(d[j].start, d[j].end, os[j], oe[j]);
-                        const bool one = nh[j] == 1 && !(c < P.min_cov);                // generic.c:961-962
-                        hit[j] = one ? (int32_t)only[j] : -1;
-                        multi = multi || nh[j] > 1;
+                        const bool h_first = h_rk[j] < g_rk[j];                        // which of the two comes first in list order
+                        const uint32_t ov1 = h_first ? h_ov[j] : g_ov[j], ov2 = h_first ? g_ov[j] : h_ov[j];
+                        const uint32_t k1 = h_first ? h_k[j] : g_k[j], k2 = h_first ? g_k[j] : h_k[j];
+                        const bool two = nh[j] == 2;
+                        const bool second = two && ov2 > ov1;
+                        const uint32_t ck = two ? (second ? k2 : k1) : h_k[j];
+                        const uint32_t cov_ov = two ? (second ? ov2 : ov1) : h_ov[j];
+                        const uint32_t qlen = d[j].end - d[j].start;
+                        const float c = __fdiv_rn((float)cov_ov, (float)qlen);          // generic.c:296-301 (qlen > 0 for any hit)
+                        const bool big = qlen >= (1u << 23);
+                        const bool simple = (nh[j] == 1 || two) && !big;
+                        hit[j] = (simple && !(c < P.min_cov)) ? (int32_t)ck : -1;       // generic.c:961-962
+                        multi = multi || (nh[j] > 0 && !simple);
                     }
-                    if (__ballot(multi)) {                                              // several hits: rare
-                        IvLds A{win, T.rank, lo_w};
+                    if (__ballot(multi)) {                                              // three or more hits / giant fragments: rare
+                        IvLds A{win};
 #pragma unroll
-                        for (int j = 0; j < RPL; j++)
-                            if (nh[j] > 1) hit[j] = itx_pick_multi(A, low[j], top[j], qs[j], qe[j], d[j].start, d[j].end, P.min_cov);
+                        for (int j = 0; j < RPL; j++) {
+                            const bool simple = (nh[j] == 1 || nh[j] == 2) && (d[j].end - d[j].start) < (1u << 23);
+                            if (nh[j] > 0 && !simple)
+                                hit[j] = itx_pick_multi(A, low[j], top[j], qs[j], qe[j], d[j].start, d[j].end, P.min_cov);
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
                         const uint32_t k = hit[j] >= 0 ? (uint32_t)hit[j] : 0u;
                         const uint4 v0 = win[2 * k], v1 = win[2 * k + 1];
-                        rec[j].s = (int32_t)v0.x; rec[j].e = (int32_t)v0.y; rec[j].pmax_e = (int32_t)v0.z; rec[j].cs = v0.w;
-                        rec[j].jcap = v1.x; rec[j].covslot = v1.y; rec[j].zslot = v1.z; rec[j].unit = v1.w;
+                        rec[j].s = (int32_t)v0.x; rec[j].e = (int32_t)v0.y; rec[j].pmax_e = (int32_t)v0.z; rec[j].rank = v0.w;
+                        rec[j].cs = v1.x; rec[j].jcap = v1.y; rec[j].covslot = v1.z; rec[j].zslot = v1.w;
                         hit[j] = hit[j] >= 0 ? hit[j] + (int32_t)lo_w : -1;
                     }
                     __builtin_amdgcn_wave_barrier();                                    // the window is rewritten next tile

@@ -188,7 +188,6 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     for (int c = 0; c < n_chrom; c++) bin_off[c + 1] = bin_off[c] + (uint32_t)(((uint64_t)chrom_size[c] >> shift) + 2);
     std::vector<uint2> bl(bin_off[n_chrom]);
     std::vector<ItxIv> iv(n_rows);
-    std::vector<uint32_t> rnk(n_rows);
     std::vector<int32_t> orig(n_rows);
     std::vector<int32_t> csize(n_chrom);
     for (int c = 0; c < n_chrom; c++) {
@@ -208,8 +207,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
             d.jcap = std::min(r.cons_end, len);
             d.covslot = unit_slot[u];
             d.zslot = unit_slot[u] + len;
-            d.unit = u;
-            rnk[k] = rank_of_row[order[k]];
+            d.rank = rank_of_row[order[k]];
             orig[k] = (int32_t)order[k];
         }
         uint32_t nb = bin_off[c + 1] - bin_off[c];
@@ -230,7 +228,6 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     ITX_HIP(hipSetDevice(device));
     Carver cv;
     const size_t o_iv = cv.take((n_rows + 1) * sizeof(ItxIv));
-    const size_t o_rank = cv.take((n_rows + 1) * 4);
     const size_t o_orig = cv.take((n_rows + 1) * 4);
     const size_t o_bl = cv.take((bl.size() + 1) * sizeof(uint2));
     const size_t o_uslot = cv.take(((size_t)n_units + 1) * 4);
@@ -248,7 +245,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         he = hipMemcpy(base + off, src, bytes, hipMemcpyHostToDevice);
         return he == hipSuccess;
     };
-    bool ok = up(o_iv, iv.data(), iv.size() * sizeof(ItxIv)) && up(o_rank, rnk.data(), rnk.size() * 4) &&
+    bool ok = up(o_iv, iv.data(), iv.size() * sizeof(ItxIv)) &&
               up(o_orig, orig.data(), orig.size() * 4) && up(o_bl, bl.data(), bl.size() * sizeof(uint2)) &&
               up(o_uslot, unit_slot.data(), unit_slot.size() * 4) && up(o_uids, unit_ids.data(), unit_ids.size() * sizeof(uint4)) &&
               up(o_ucov, unit_covoff.data(), unit_covoff.size() * 8);
@@ -272,7 +269,6 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     t->d_all = base;
     t->table_bytes = total;
     t->dev.iv = (const ItxIv *)(base + o_iv);
-    t->dev.rank = (const uint32_t *)(base + o_rank);
     t->dev.orig = (const int32_t *)(base + o_orig);
     t->dev.bl = (const uint2 *)(base + o_bl);
     t->dev.shift = shift;

@@ -58,7 +58,8 @@ struct ItxAccumLayout {
 static inline ItxAccumLayout itx_accum_layout(uint64_t n_slots, uint64_t n_rows)
 {
     ItxAccumLayout L;
-    L.a_all = 0; L.a_uniq = n_slots; L.b_all = 2 * n_slots; L.b_uniq = 3 * n_slots; L.locus = 4 * n_slots;
+    const uint64_t st = (n_slots + 63) & ~uint64_t(63);      // each array starts 256-byte aligned (16-byte vector updates)
+    L.a_all = 0; L.a_uniq = st; L.b_all = 2 * st; L.b_uniq = 3 * st; L.locus = 4 * st;
     L.n_u32 = L.locus + n_rows;
     return L;
 }

@@ -31,7 +31,7 @@
 #define HB 1024             // threads per workgroup (hist): 2 workgroups per CU keep 32 waves in flight
 #define ITX_LOGW 13         // slots per partition (W = 8192): LDS window of k_hist = W * 8 bytes = 64 KiB
 #define ITX_W (1u << ITX_LOGW)
-#define ITX_CHUNK 32768u    // max keys per k_hist item: keeps the packed 16-bit halves from overflowing
+#define ITX_CHUNK 65535u    // max keys per k_hist item: keeps the packed 16-bit halves from overflowing
 #define ITX_MAXP 4096u      // partitions the LDS histograms / the plan kernel are sized for
 #define ITX_SUB ITX_PART_SUB // sub-cursors per partition
 
@@ -168,18 +168,27 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint32_t *__restrict__ key
     const uint32_t total = blk_cnt[blockIdx.x];
     const uint32_t *in = keys0 + 2 * (size_t)blockIdx.x * span;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rounds = (total + PB - 1) / PB;
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t idx = r * PB + threadIdx.x;
-        const bool has = idx < total;
-        const uint32_t key = has ? in[idx] : 0xffffffffu;
-        const uint32_t p = has ? key >> (2 + ITX_LOGW) : 0xffffffffu;
-        uint32_t len, leader;
-        const bool st = wave_run(p, has, lane, &len, &leader);
-        uint32_t base = 0;
-        if (st) base = atomicAdd(&s_cur[p], len);             // one returning LDS add per run
-        base = (uint32_t)__shfl((int32_t)base, (int)leader, 64);
-        if (has) keys1[base + (lane - leader)] = key;
+    // 8 rounds of 256 keys per iteration: the loads of all eight are in flight before the first is used
+    // (one round after the other leaves the kernel waiting on one global load per 256 keys per workgroup)
+    constexpr int U = 8;
+    for (uint32_t r0 = 0; r0 < total; r0 += U * PB) {
+        uint32_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t idx = r0 + u * PB + threadIdx.x;
+            key[u] = idx < total ? in[idx] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool has = key[u] != 0xffffffffu;
+            const uint32_t p = has ? key[u] >> (2 + ITX_LOGW) : 0xffffffffu;
+            uint32_t len, leader;
+            const bool st = wave_run(p, has, lane, &len, &leader);
+            uint32_t base = 0;
+            if (st) base = atomicAdd(&s_cur[p], len);             // one returning LDS add per run
+            base = (uint32_t)__shfl((int32_t)base, (int)leader, 64);
+            if (has) keys1[base + (lane - leader)] = key[u];
+        }
     }
 }
 
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
                                              const uint32_t *__restrict__ n_items, uint32_t *__restrict__ u32, ItxAccumLayout L,
                                              uint32_t n_slots)
 {
-    __shared__ uint32_t s_a[ITX_W], s_b[ITX_W];               // packed all:16 | uniq:16
+    __shared__ __attribute__((aligned(16))) uint32_t s_a[ITX_W], s_b[ITX_W];   // packed all:16 | uniq:16
     const uint32_t nI = *n_items;
     for (uint32_t it = blockIdx.x; it < nI; it += gridDim.x) {
         const uint4 item = items[it];
@@ -198,29 +207,75 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
             s_b[k] = 0;
         }
         __syncthreads();
-        for (uint32_t k = item.y + threadIdx.x; k < item.z; k += HB) {
-            const uint32_t key = keys1[k];
-            const uint32_t sl = (key >> 2) - slot0;
-            const uint32_t v = 1u | ((key & 1u) << 16);
-            if (key & 2u) atomicAdd(&s_b[sl], v); else atomicAdd(&s_a[sl], v);
+        for (uint32_t k0 = item.y; k0 < item.z; k0 += 4 * HB) {          // 4 loads in flight per thread
+            uint32_t key[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = k0 + u * HB + threadIdx.x;
+                key[u] = k < item.z ? keys1[k] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (key[u] != 0xffffffffu) {
+                    const uint32_t sl = (key[u] >> 2) - slot0;
+                    const uint32_t v = 1u | ((key[u] & 1u) << 16);
+                    if (key[u] & 2u) atomicAdd(&s_b[sl], v); else atomicAdd(&s_a[sl], v);
+                }
+            }
         }
         __syncthreads();
         uint32_t lim = n_slots - slot0;
         if (lim > ITX_W) lim = ITX_W;
         if (item.w) {
-            // this item owns the partition: plain read-modify-write, coalesced
-            for (uint32_t k = threadIdx.x; k < lim; k += HB) {
-                const uint32_t a = s_a[k], b = s_b[k];
-                if (a) {
-                    u32[L.a_all + slot0 + k] += a & 0xffffu;
-                    if (a >> 16) u32[L.a_uniq + slot0 + k] += a >> 16;
-                }
-                if (b) {
-                    u32[L.b_all + slot0 + k] += b & 0xffffu;
-                    if (b >> 16) u32[L.b_uniq + slot0 + k] += b >> 16;
+            // this item owns the partition: plain read-modify-write, 4 consecutive slots per thread (16-byte accesses;
+            // the arrays start 256-byte aligned and slot0 is a multiple of the window)
+            for (uint32_t k = 4 * threadIdx.x; k < ITX_W; k += 4 * HB) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(&s_a[k]);
+                const uint4 b = *reinterpret_cast<const uint4 *>(&s_b[k]);
+                const bool anya = (a.x | a.y | a.z | a.w) != 0, anyb = (b.x | b.y | b.z | b.w) != 0;
+                if (!(anya || anyb)) continue;
+                const size_t g = (size_t)slot0 + k;
+                if (k + 4 <= lim) {
+                    if (anya) {
+                        uint4 x = *reinterpret_cast<uint4 *>(&u32[L.a_all + g]);
+                        x.x += a.x & 0xffffu; x.y += a.y & 0xffffu; x.z += a.z & 0xffffu; x.w += a.w & 0xffffu;
+                        *reinterpret_cast<uint4 *>(&u32[L.a_all + g]) = x;
+                        if ((a.x | a.y | a.z | a.w) >> 16) {
+                            uint4 y = *reinterpret_cast<uint4 *>(&u32[L.a_uniq + g]);
+                            y.x += a.x >> 16; y.y += a.y >> 16; y.z += a.z >> 16; y.w += a.w >> 16;
+                            *reinterpret_cast<uint4 *>(&u32[L.a_uniq + g]) = y;
+                        }
+                    }
+                    if (anyb) {
+                        uint4 x = *reinterpret_cast<uint4 *>(&u32[L.b_all + g]);
+                        x.x += b.x & 0xffffu; x.y += b.y & 0xffffu; x.z += b.z & 0xffffu; x.w += b.w & 0xffffu;
+                        *reinterpret_cast<uint4 *>(&u32[L.b_all + g]) = x;
+                        if ((b.x | b.y | b.z | b.w) >> 16) {
+                            uint4 y = *reinterpret_cast<uint4 *>(&u32[L.b_uniq + g]);
+                            y.x += b.x >> 16; y.y += b.y >> 16; y.z += b.z >> 16; y.w += b.w >> 16;
+                            *reinterpret_cast<uint4 *>(&u32[L.b_uniq + g]) = y;
+                        }
+                    }
+                } else {                                         // the last, partial group of the slot space
+                    const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (k + i < lim) {
+                            if (av[i]) {
+                                u32[L.a_all + g + i] += av[i] & 0xffffu;
+                                u32[L.a_uniq + g + i] += av[i] >> 16;
+                            }
+                            if (bv[i]) {
+                                u32[L.b_all + g + i] += bv[i] & 0xffffu;
+                                u32[L.b_uniq + g + i] += bv[i] >> 16;
+                            }
+                        }
+                    }
                 }
             }
         } else {
+            // one of several items of a hot partition: many keys per slot, so few distinct slots per key — atomics,
+            // lane-contiguous so that a wave's adds fall into as few 64-byte requests as possible
             for (uint32_t k = threadIdx.x; k < lim; k += HB) {
                 const uint32_t a = s_a[k], b = s_b[k];
                 if (a) {

@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 }
 
 template <int WHAT>
-__global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
+__global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
                                                int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64,
                                                uint32_t *__restrict__ u32, ItxAccumLayout L, uint32_t *__restrict__ keys0,
                                                uint32_t *__restrict__ blk_cnt, ItxEmitPlan E)
@@ -440,18 +440,10 @@ __global__ __launch_bounds__(SB) void k_stream(ItxDevTable T, ItxRunParams P, It
                 base += (uint32_t)__popcll(mA[j]);
                 if (hB[j]) out[base + (uint32_t)__popcll(mB[j] & lt)] = kB[j];
                 base += (uint32_t)__popcll(mB[j]);
-                // keys per partition: one LDS add per run of equal start-key partitions (coordinate-sorted input: long
-                // runs); an end key almost always falls in its start key's partition and rides along
-                uint32_t len, leader;
-                const uint32_t pA = kA[j] >> (2 + E.log_w), pB = kB[j] >> (2 + E.log_w);
-                const bool st = wave_run(pA, hA[j], lane, &len, &leader);
-                const bool b_same = hB[j] && pB == pA;
-                const unsigned long long m_same = __ballot(b_same);
-                if (st) {
-                    const unsigned long long run = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << lane;
-                    atomicAdd(&s_pc[pA], len + (uint32_t)__popcll(m_same & run));
-                }
-                if (hB[j] && !b_same) atomicAdd(&s_pc[pB], 1u);
+                // keys per partition of this workgroup's region (LDS adds to equal addresses serialise in the LDS
+                // pipeline, beside the VALU work, which is what bounds this kernel)
+                if (hA[j]) atomicAdd(&s_pc[kA[j] >> (2 + E.log_w)], 1u);
+                if (hB[j]) atomicAdd(&s_pc[kB[j] >> (2 + E.log_w)], 1u);
             }
         }
     }

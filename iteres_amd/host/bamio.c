@@ -1,0 +1,397 @@
+/* bamio.c — alignment input for the host: BGZF/BAM and SAM text decoded straight into the engine's pinned
+ * record SoA (tid, pos, tmpend, mapq, flag5, mpos, isize). Follows the file formats and, where behaviour is
+ * observable, samtools 0.1.18 as vendored by the reference: bgzf.c:401-411,471-565 (block framing), bam.c:69-109
+ * (header), bam.c:179-210 (record), bam.c:17-27 (bam_calend: only M, D, N advance), bam_aux.c:36-48 (aux walk),
+ * bam_import.c:237-330 (SAM text; a mapped record without CIGAR is flagged unmapped). */
+#define _GNU_SOURCE
+#include "itx_host.h"
+
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#define BGZF_MAX 0x10000
+
+struct aln_reader {
+    FILE *f;
+    int is_sam;
+    /* header */
+    int n_targets;
+    char **tname;
+    names_t tnames;
+    /* BGZF state */
+    uint8_t *cbuf, *ubuf;
+    size_t ulen, upos;
+    int eof;
+    /* record scratch */
+    uint8_t *rec;
+    size_t rec_cap;
+    /* SAM state */
+    char *line;
+    size_t line_cap;
+    ssize_t pending_len;     /* first alignment line read while scanning the header, -1 none */
+    long long n_lines;
+};
+
+/* ---- BGZF ------------------------------------------------------------------------------------------------ */
+static int bgzf_next_block(aln_reader *r)
+{
+    uint8_t hdr[18];
+    for (;;) {
+        size_t got = fread(hdr, 1, 18, r->f);
+        if (got == 0) {
+            r->eof = 1;
+            return 0;
+        }
+        /* bgzf.c:401-411 check_header: gzip member with exactly one 6-byte extra field "BC" */
+        if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4) || (hdr[10] | hdr[11] << 8) != 6 ||
+            hdr[12] != 'B' || hdr[13] != 'C' || (hdr[14] | hdr[15] << 8) != 2) {
+            r->eof = 1;
+            return -1;
+        }
+        const size_t bsize = (size_t)(hdr[16] | hdr[17] << 8) + 1;
+        if (bsize < 26) {
+            r->eof = 1;
+            return -1;
+        }
+        const size_t rest = bsize - 18;
+        if (fread(r->cbuf, 1, rest, r->f) != rest) {
+            r->eof = 1;
+            return -1;
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        zs.next_in = r->cbuf;
+        zs.avail_in = (uInt)(rest - 8);
+        zs.next_out = r->ubuf;
+        zs.avail_out = BGZF_MAX;
+        if (inflateInit2(&zs, -15) != Z_OK) return -1;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END) {
+            r->eof = 1;
+            return -1;
+        }
+        r->ulen = zs.total_out;
+        r->upos = 0;
+        if (r->ulen) return 1;       /* empty blocks (the EOF marker) are skipped */
+    }
+}
+
+static size_t bgzf_read(aln_reader *r, void *dst, size_t n)
+{
+    size_t done = 0;
+    while (done < n) {
+        if (r->upos == r->ulen) {
+            if (r->eof || bgzf_next_block(r) <= 0) break;
+        }
+        size_t k = r->ulen - r->upos;
+        if (k > n - done) k = n - done;
+        memcpy((uint8_t *)dst + done, r->ubuf + r->upos, k);
+        r->upos += k;
+        done += k;
+    }
+    return done;
+}
+
+static int32_t rd_i32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
+static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+static void add_target(aln_reader *r, const char *name)
+{
+    r->tname = xrealloc(r->tname, sizeof(char *) * (size_t)(r->n_targets + 1));
+    r->tname[r->n_targets++] = xstrdup(name);
+}
+
+static int bam_read_header(aln_reader *r)
+{
+    uint8_t b[8];
+    if (bgzf_read(r, b, 4) != 4 || memcmp(b, "BAM\1", 4) != 0) {
+        fprintf(stderr, "[bam_header_read] invalid BAM binary header (this is not a BAM file).\n");
+        return -1;
+    }
+    if (bgzf_read(r, b, 4) != 4) return -1;
+    int32_t l_text = rd_i32(b);
+    while (l_text > 0) {                     /* the text header is not needed: tids come from the binary list */
+        uint8_t skip[4096];
+        size_t k = (size_t)l_text < sizeof skip ? (size_t)l_text : sizeof skip;
+        if (bgzf_read(r, skip, k) != k) return -1;
+        l_text -= (int32_t)k;
+    }
+    if (bgzf_read(r, b, 4) != 4) return -1;
+    const int32_t n_ref = rd_i32(b);
+    for (int32_t i = 0; i < n_ref; i++) {
+        if (bgzf_read(r, b, 4) != 4) return -1;
+        const int32_t l_name = rd_i32(b);
+        if (l_name <= 0 || l_name > 1 << 20) return -1;
+        char *nm = xmalloc((size_t)l_name + 1);
+        if (bgzf_read(r, nm, (size_t)l_name) != (size_t)l_name) {
+            free(nm);
+            return -1;
+        }
+        nm[l_name] = 0;
+        add_target(r, nm);
+        free(nm);
+        if (bgzf_read(r, b, 4) != 4) return -1;     /* l_ref */
+    }
+    return 0;
+}
+
+/* ---- SAM text header ------------------------------------------------------------------------------------- */
+static int sam_read_header(aln_reader *r)
+{
+    r->pending_len = -1;
+    ssize_t len;
+    while ((len = getline(&r->line, &r->line_cap, r->f)) >= 0) {
+        r->n_lines++;
+        if (r->line[0] != '@') {
+            r->pending_len = len;
+            break;
+        }
+        if (strncmp(r->line, "@SQ", 3) == 0) {
+            char *sn = strstr(r->line, "\tSN:");
+            if (sn) {
+                sn += 4;
+                size_t k = strcspn(sn, "\t\r\n");
+                char *nm = xmalloc(k + 1);
+                memcpy(nm, sn, k);
+                nm[k] = 0;
+                add_target(r, nm);
+                free(nm);
+            }
+        }
+    }
+    return 0;
+}
+
+aln_reader *aln_open(const char *path, int is_sam)
+{
+    FILE *f = fopen(path, is_sam ? "r" : "rb");
+    if (!f) return NULL;
+    aln_reader *r = xcalloc(1, sizeof *r);
+    r->f = f;
+    r->is_sam = is_sam;
+    r->pending_len = -1;
+    names_init(&r->tnames);
+    int rc;
+    if (is_sam) {
+        rc = sam_read_header(r);
+    } else {
+        r->cbuf = xmalloc(BGZF_MAX + 64);
+        r->ubuf = xmalloc(BGZF_MAX + 64);
+        rc = bam_read_header(r);
+    }
+    if (rc != 0) {
+        aln_close(r);
+        return NULL;
+    }
+    for (int i = 0; i < r->n_targets; i++) names_intern(&r->tnames, r->tname[i]);    /* first occurrence wins a lookup */
+    return r;
+}
+
+void aln_close(aln_reader *r)
+{
+    if (!r) return;
+    if (r->f) fclose(r->f);
+    for (int i = 0; i < r->n_targets; i++) free(r->tname[i]);
+    free(r->tname);
+    names_free(&r->tnames);
+    free(r->cbuf);
+    free(r->ubuf);
+    free(r->rec);
+    free(r->line);
+    free(r);
+}
+
+int aln_n_targets(const aln_reader *r) { return r->n_targets; }
+const char *aln_target_name(const aln_reader *r, int tid) { return r->tname[tid]; }
+
+/* bam_aux.c:36-48: does the aux block hold tag `t0 t1`? */
+static int aux_has_tag(const uint8_t *s, const uint8_t *end, char t0, char t1)
+{
+    while (s + 3 <= end) {
+        const int hit = s[0] == (uint8_t)t0 && s[1] == (uint8_t)t1;
+        const int type = toupper(s[2]);
+        s += 3;
+        if (hit) return 1;
+        if (type == 'A' || type == 'C') s += 1;
+        else if (type == 'S') s += 2;
+        else if (type == 'I' || type == 'F') s += 4;
+        else if (type == 'D') s += 8;
+        else if (type == 'Z' || type == 'H') {
+            while (s < end && *s) ++s;
+            ++s;
+        } else if (type == 'B') {
+            if (s + 5 > end) return 0;
+            const int sub = toupper(s[0]);
+            const uint32_t cnt = rd_u32(s + 1);
+            const size_t esz = (sub == 'C' || sub == 'A') ? 1 : (sub == 'S') ? 2 : 4;
+            s += 5 + (size_t)cnt * esz;
+        } else
+            return 0;
+    }
+    return 0;
+}
+
+static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa)
+{
+    size_t n = 0;
+    uint8_t b4[4], core[32];
+    while (n < cap) {
+        if (bgzf_read(r, b4, 4) != 4) break;                         /* bam.c:186-187 */
+        const int32_t block_len = rd_i32(b4);
+        if (block_len < 32) break;
+        if (bgzf_read(r, core, 32) != 32) break;                     /* bam.c:190 */
+        const size_t dlen = (size_t)block_len - 32;
+        if (dlen > r->rec_cap) {
+            r->rec_cap = dlen * 2 + 256;
+            r->rec = xrealloc(r->rec, r->rec_cap);
+        }
+        if (bgzf_read(r, r->rec, dlen) != dlen) break;               /* bam.c:205 */
+        const int32_t tid = rd_i32(core), pos = rd_i32(core + 4);
+        const uint32_t x1 = rd_u32(core + 8), x2 = rd_u32(core + 12);
+        const uint32_t l_qname = x1 & 0xff, qual = (x1 >> 8) & 0xff, flag = x2 >> 16, n_cigar = x2 & 0xffff;
+        const int32_t l_qseq = rd_i32(core + 16), mpos = rd_i32(core + 24), isize = rd_i32(core + 28);
+        int32_t tmpend;
+        if (n_cigar && (size_t)l_qname + 4 * (size_t)n_cigar <= dlen) {
+            uint32_t e = (uint32_t)pos;                               /* bam.c:17-27 */
+            const uint8_t *cg = r->rec + l_qname;
+            for (uint32_t k = 0; k < n_cigar; k++) {
+                const uint32_t c = rd_u32(cg + 4 * k), op = c & 0xf;
+                if (op == 0 || op == 2 || op == 3) e += c >> 4;       /* M, D, N */
+            }
+            tmpend = (int32_t)e;
+        } else {
+            tmpend = (int32_t)((uint32_t)pos + (uint32_t)l_qseq);     /* generic.c:820 */
+        }
+        st->tid[n] = tid;
+        st->pos[n] = pos;
+        st->tmpend[n] = tmpend;
+        st->mapq[n] = (uint8_t)qual;
+        st->flag5[n] = ITX_FLAG5(flag);
+        st->mpos[n] = mpos;
+        st->isize[n] = isize;
+        if (flag & 1) *any_paired = 1;
+        if (qnames) qnames[n] = xstrdup(l_qname && l_qname <= dlen ? (const char *)r->rec : "");
+        if (!*aux_xa) {
+            const size_t off = (size_t)l_qname + 4 * (size_t)n_cigar + ((size_t)(l_qseq > 0 ? l_qseq : 0) + 1) / 2 + (size_t)(l_qseq > 0 ? l_qseq : 0);
+            if (off < dlen && aux_has_tag(r->rec + off, r->rec + dlen, 'X', 'A')) *aux_xa = 1;
+        }
+        n++;
+    }
+    return n;
+}
+
+/* bam_import.c: the textual flag letters of samtools 0.1.x ("pPuUrR12sfd") */
+static unsigned flag_from_chars(const char *s)
+{
+    unsigned f = 0;
+    for (; *s; ++s) {
+        switch (*s) {
+        case 'p': f |= 0x1; break;
+        case 'P': f |= 0x2; break;
+        case 'u': f |= 0x4; break;
+        case 'U': f |= 0x8; break;
+        case 'r': f |= 0x10; break;
+        case 'R': f |= 0x20; break;
+        case '1': f |= 0x40; break;
+        case '2': f |= 0x80; break;
+        case 's': f |= 0x100; break;
+        case 'f': f |= 0x200; break;
+        case 'd': f |= 0x400; break;
+        default: break;
+        }
+    }
+    return f;
+}
+
+static size_t sam_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa)
+{
+    size_t n = 0;
+    while (n < cap) {
+        ssize_t len;
+        if (r->pending_len >= 0) {
+            len = r->pending_len;
+            r->pending_len = -1;
+        } else {
+            len = getline(&r->line, &r->line_cap, r->f);
+            if (len < 0) break;
+            r->n_lines++;
+        }
+        while (len > 0 && (r->line[len - 1] == '\n' || r->line[len - 1] == '\r')) r->line[--len] = 0;
+        if (len == 0) continue;                                          /* empty lines are skipped */
+        char *fld[12];
+        int nf = 0;
+        char *p = r->line;
+        while (nf < 12) {
+            fld[nf++] = p;
+            if (nf == 12) break;                                         /* the 12th "field" keeps all optional fields */
+            char *t = strchr(p, '\t');
+            if (!t) break;
+            *t = 0;
+            p = t + 1;
+        }
+        if (nf < 11) break;                                              /* truncated line: the parser gives up */
+        char *endp;
+        long flag = strtol(fld[1], &endp, 0);
+        if (*endp) flag = (long)flag_from_chars(fld[1]);
+        int32_t tid = -1;
+        if (strcmp(fld[2], "*") != 0) {
+            const int64_t t = names_find(&r->tnames, fld[2]);
+            if (t < 0) {
+                if (r->n_targets == 0) {
+                    fprintf(stderr, "[sam_read1] missing header? Abort!\n");
+                    exit(1);
+                }
+                fprintf(stderr, "[sam_read1] reference '%s' is recognized as '*'.\n", fld[2]);
+            }
+            tid = (int32_t)t;
+        }
+        const int32_t pos = isdigit((unsigned char)fld[3][0]) ? atoi(fld[3]) - 1 : -1;
+        const int qual = isdigit((unsigned char)fld[4][0]) ? atoi(fld[4]) : 0;
+        uint32_t e = (uint32_t)pos;
+        int n_cigar = 0;
+        if (fld[5][0] != '*') {
+            const char *s = fld[5];
+            while (*s) {
+                char *t;
+                const long x = strtol(s, &t, 10);
+                const int op = toupper((unsigned char)*t);
+                if (!*t) break;
+                if (op == 'M' || op == 'D' || op == 'N') e += (uint32_t)x;
+                n_cigar++;
+                s = t + 1;
+            }
+        } else if (!(flag & 0x4)) {
+            fprintf(stderr, "Parse warning at line %lld: mapped sequence without CIGAR\n", r->n_lines);
+            flag |= 0x4;
+        }
+        const int32_t mpos = isdigit((unsigned char)fld[7][0]) ? atoi(fld[7]) - 1 : -1;
+        const int32_t isize = (fld[8][0] == '-' || isdigit((unsigned char)fld[8][0])) ? atoi(fld[8]) : 0;
+        const int32_t l_qseq = strcmp(fld[9], "*") == 0 ? 0 : (int32_t)strlen(fld[9]);
+        st->tid[n] = tid;
+        st->pos[n] = pos;
+        st->tmpend[n] = n_cigar ? (int32_t)e : (int32_t)((uint32_t)pos + (uint32_t)l_qseq);
+        st->mapq[n] = (uint8_t)qual;
+        st->flag5[n] = ITX_FLAG5((unsigned)flag);
+        st->mpos[n] = mpos;
+        st->isize[n] = isize;
+        if (flag & 1) *any_paired = 1;
+        if (qnames) qnames[n] = xstrdup(fld[0]);
+        if (!*aux_xa && nf == 12) {
+            for (char *a = fld[11]; a; a = strchr(a, '\t') ? strchr(a, '\t') + 1 : NULL)
+                if (strncmp(a, "XA:", 3) == 0) {
+                    *aux_xa = 1;
+                    break;
+                }
+        }
+        n++;
+    }
+    return n;
+}
+
+size_t aln_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa)
+{
+    return r->is_sam ? sam_read_batch(r, st, cap, qnames, any_paired, aux_xa) : bam_read_batch(r, st, cap, qnames, any_paired, aux_xa);
+}

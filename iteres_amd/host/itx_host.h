@@ -1,0 +1,107 @@
+/* itx_host.h — the C host side of the drop-in: `iteres stat` / `iteres filter` with the reference's command
+ * line, stderr banners, exit codes and output file formats (stat.c, filter.c, generic.c:53-113,1709-1746 of
+ * /root/reference), driving the MI355X engine through include/iteres_amd.h. Everything here is host logic:
+ * parsing, name bookkeeping in the reference's hash iteration order, BAM/SAM decoding into the pinned record
+ * SoA, and the writers. There is no CPU implementation of the hot path in this program. */
+#ifndef ITX_HOST_H
+#define ITX_HOST_H
+#include <stdint.h>
+#include <stdio.h>
+#include <stddef.h>
+
+#include "../../include/iteres_amd.h"
+
+#define ITERES_VERSION "0.3.3-r123"      /* generic.h:4 of the reference: same version string in the usage text */
+
+/* ---- errors: cuskent/errabort.c:166-199 — message + newline to stderr, exit(-1) */
+void die(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)));
+void warnf(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void *xmalloc(size_t n);
+void *xcalloc(size_t n, size_t sz);
+void *xrealloc(void *p, size_t n);
+char *xstrdup(const char *s);
+
+/* ---- string -> dense id table that remembers insertion order and can list its names in the iteration
+ * order of a kent hash (cuskent/hash.c:41-53,115-142,374-410,511-552) built by the same insertions. */
+typedef struct {
+    char **name;
+    uint32_t n, cap;
+    uint32_t *bucket;      /* open hashing for lookups */
+    uint32_t *next;
+    uint32_t nbucket;
+} names_t;
+void names_init(names_t *t);
+void names_free(names_t *t);
+int64_t names_find(const names_t *t, const char *s);
+uint32_t names_intern(names_t *t, const char *s);             /* id of s, adding it when new */
+uint32_t kent_hash_string(const char *s);                     /* cuskent/hash.c:41-53 */
+/* order[i] = id of the i-th name hashFirst/hashNext would visit (hash started with 2^start_pow2 buckets). */
+void names_kent_order(const names_t *t, int start_pow2, uint32_t *order);
+
+/* ---- two-column "name value" files (cuskent/obscure.c:139-150 hashNameIntFile): later duplicates win */
+typedef struct {
+    names_t names;
+    int64_t *value;
+} sizes_t;
+void sizes_load(const char *path, sizes_t *out);
+void sizes_free(sizes_t *s);
+/* value of name or dflt (hashIntValDefault, cuskent/hash.c:250-258) */
+int64_t sizes_get(const sizes_t *s, const char *name, int64_t dflt);
+
+/* ---- rmsk.txt -> rows + name tables (generic.c:1578-1707 without the binKeeper) */
+typedef struct {
+    names_t chroms;            /* chromosomes that got a binKeeper, in first-seen order: key order of hashRmsk   */
+    names_t reps, fams, clas;  /* hashRep / hashFam / hashCla insertion order                                     */
+    itx_row *rows;             /* kept rows, file order; .chrom indexes chrom_size                                */
+    uint32_t *row_chrom_name;  /* [n_rows] index into chroms                                                      */
+    size_t n_rows;
+    int64_t *chrom_size;       /* [chroms.n] size from the chrom-size file                                        */
+    uint32_t *rep_len;         /* [reps.n]  repeat-size file value or 0 (generic.c:1647)                          */
+    uint32_t *rep_fam, *rep_cla;   /* family / class string ids of the FIRST row of each name (generic.c:1638-1640) */
+    uint32_t *fam_cla;         /* class of the first row of each family (generic.c:1667-1668)                     */
+    uint64_t *rep_genome, *rep_total, *fam_genome, *fam_total, *cla_genome, *cla_total;   /* genome_count, total_length */
+    int repeat_num;            /* rows counted by the banner (generic.c:1593,1697)                                */
+} rmsk_t;
+void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_sizes, int filter_field, const char *filter_name,
+               rmsk_t *out);
+void rmsk_free(rmsk_t *r);
+
+/* ---- alignment input: BAM (BGZF) or SAM text, decoded into the engine's record SoA */
+typedef struct aln_reader aln_reader;
+aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the file cannot be opened / has no header */
+void aln_close(aln_reader *r);
+int aln_n_targets(const aln_reader *r);
+const char *aln_target_name(const aln_reader *r, int tid);
+/* Fills up to cap records of the staging slot; returns the number read (0 at end of input).
+ * qnames: when non-NULL, receives malloc'd copies of the read names (filter -r).
+ * *any_paired is set when a record with the PAIRED flag was seen; *aux_xa when a record carries an XA tag. */
+size_t aln_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa);
+
+/* ---- shared by the two drivers */
+typedef struct {
+    int is_sam, add_chr, treat, discard, keep_wig, xa_veto, dedup;
+    unsigned mapq, isize, extension;
+    float min_cov;
+    const char *chr_size_file, *rep_size_file, *rmsk_file, *aln_arg;
+} run_opts;
+/* generic.c:7-15 */
+char *filename_without_ext(const char *path);
+/* Runs the record loop (generic.c:700-1062 / 343-697) over one or more files through the engine.
+ * progress_every: 100000 (stat, generic.c:760) or 10000 (filter, generic.c:397). want_qnames: per-locus read
+ * names (filter -r): *locus_names[row] receives a comma-joined list in BAM order. */
+void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
+                unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names);
+
+/* writers (generic.c:35-41,53-113,1709-1746) */
+double cal_rpkm(unsigned long long reads, unsigned long long total_length, unsigned long long mapped);
+double cal_rpm(unsigned long long reads, unsigned long long mapped);
+void write_report(const char *path, const uint64_t *cnt, unsigned mapq, const char *subfam);
+void write_wig_and_stat(const rmsk_t *rm, const itx_result *res, const uint64_t *cov_off, const char *f_stat, const char *f_wig,
+                        const char *f_fam, const char *f_cla, const char *f_wig_uniq, unsigned long long reads_num,
+                        unsigned long long reads_num_unique);
+void write_filter_out(const rmsk_t *rm, const uint32_t *locus_cnt, char **locus_names, const char *path, int readlist, int threshold,
+                      const char *subfam, unsigned long long reads_num);
+
+int main_stat(int argc, char **argv);
+int main_filter(int argc, char **argv);
+#endif

@@ -1,0 +1,34 @@
+/* main.c — command dispatch of the drop-in `iteres` (iteres.c:3-29 of the reference). stat and filter are the
+ * hot-path commands rebuilt on the MI355X engine; cpgstat / cpgfilter (bedGraph input, floating-point sums) are
+ * outside this build's scope and say so. */
+#include "itx_host.h"
+
+#include <string.h>
+
+static int usage(void)
+{
+    fprintf(stderr, "\n");
+    fprintf(stderr, "Program: iteres (repeat analysis utils from Wang lab)\n");
+    fprintf(stderr, "Version: %s\n\n", ITERES_VERSION);
+    fprintf(stderr, "Usage:   iteres <command> [options]\n\n");
+    fprintf(stderr, "Command: stat        get repeat alignment statistics\n");
+    fprintf(stderr, "         filter      filter alignment statistic on repName/repFamily/repClass\n");
+    fprintf(stderr, "         cpgstat     generate CpG density from MRE-Seq data for repeats\n");
+    fprintf(stderr, "         cpgfilter   filter CpG statistic on repName/repFamily/repClass\n");
+    fprintf(stderr, "\n");
+    return 1;
+}
+
+int main(int argc, char *argv[])
+{
+    if (argc < 2) return usage();
+    if (strcmp(argv[1], "stat") == 0) return main_stat(argc - 1, argv + 1);
+    else if (strcmp(argv[1], "filter") == 0) return main_filter(argc - 1, argv + 1);
+    else if (strcmp(argv[1], "cpgstat") == 0 || strcmp(argv[1], "cpgfilter") == 0) {
+        fprintf(stderr, "[iteres] '%s' is not part of the MI355X build (only stat and filter are); use the reference binary for it\n", argv[1]);
+        return 1;
+    } else {
+        fprintf(stderr, "[iteres] unrecognized command '%s'\n", argv[1]);
+        return 1;
+    }
+}

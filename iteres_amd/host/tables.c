@@ -1,0 +1,407 @@
+/* tables.c — error helpers, name tables in kent-hash iteration order, the two-column size files and the
+ * rmsk.txt loader. Restates what stat.c:137-141 / filter.c:121-125 set up before the record loop:
+ * hashNameIntFile (cuskent/obscure.c:139-150) and rmsk2binKeeperHash (generic.c:1578-1707), minus the
+ * binKeeper itself, which lives on the GPU (itx_table_create). */
+#define _GNU_SOURCE
+#include "itx_host.h"
+
+#include <ctype.h>
+#include <errno.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+void die(const char *fmt, ...)
+{
+    va_list ap;
+    fflush(stdout);
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+    exit(-1);
+}
+
+void warnf(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+
+void *xmalloc(size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (!p) die("Out of memory needMem - request size %llu bytes", (unsigned long long)n);
+    return p;
+}
+void *xcalloc(size_t n, size_t sz)
+{
+    void *p = calloc(n ? n : 1, sz ? sz : 1);
+    if (!p) die("Out of memory needMem - request size %llu bytes", (unsigned long long)(n * sz));
+    return p;
+}
+void *xrealloc(void *p, size_t n)
+{
+    void *q = realloc(p, n ? n : 1);
+    if (!q) die("Out of memory needMoreMem - request size %llu bytes", (unsigned long long)n);
+    return q;
+}
+char *xstrdup(const char *s)
+{
+    size_t n = strlen(s) + 1;
+    char *p = xmalloc(n);
+    memcpy(p, s, n);
+    return p;
+}
+
+/* -------------------------------------------------------------------------------------------- names */
+uint32_t kent_hash_string(const char *s)
+{
+    uint32_t r = 0;
+    int c;
+    while ((c = *s++) != '\0') r += (r << 3) + (uint32_t)c;     /* plain char: signed on x86-64, as in the reference */
+    return r;
+}
+
+void names_init(names_t *t)
+{
+    memset(t, 0, sizeof *t);
+    t->nbucket = 1024;
+    t->bucket = xmalloc(sizeof(uint32_t) * t->nbucket);
+    memset(t->bucket, 0xff, sizeof(uint32_t) * t->nbucket);
+}
+
+void names_free(names_t *t)
+{
+    for (uint32_t i = 0; i < t->n; i++) free(t->name[i]);
+    free(t->name);
+    free(t->bucket);
+    free(t->next);
+    memset(t, 0, sizeof *t);
+}
+
+int64_t names_find(const names_t *t, const char *s)
+{
+    if (!t->nbucket) return -1;
+    for (uint32_t i = t->bucket[kent_hash_string(s) & (t->nbucket - 1)]; i != 0xffffffffu; i = t->next[i])
+        if (strcmp(t->name[i], s) == 0) return i;
+    return -1;
+}
+
+uint32_t names_intern(names_t *t, const char *s)
+{
+    int64_t f = names_find(t, s);
+    if (f >= 0) return (uint32_t)f;
+    if (t->n == t->cap) {
+        t->cap = t->cap ? t->cap * 2 : 256;
+        t->name = xrealloc(t->name, sizeof(char *) * t->cap);
+        t->next = xrealloc(t->next, sizeof(uint32_t) * t->cap);
+    }
+    if (t->n >= t->nbucket) {                              /* keep chains short */
+        t->nbucket *= 4;
+        t->bucket = xrealloc(t->bucket, sizeof(uint32_t) * t->nbucket);
+        memset(t->bucket, 0xff, sizeof(uint32_t) * t->nbucket);
+        for (uint32_t i = 0; i < t->n; i++) {
+            uint32_t b = kent_hash_string(t->name[i]) & (t->nbucket - 1);
+            t->next[i] = t->bucket[b];
+            t->bucket[b] = i;
+        }
+    }
+    uint32_t id = t->n++;
+    t->name[id] = xstrdup(s);
+    uint32_t b = kent_hash_string(s) & (t->nbucket - 1);
+    t->next[id] = t->bucket[b];
+    t->bucket[b] = id;
+    return id;
+}
+
+struct ko {
+    uint32_t bucket, id;
+};
+static int ko_cmp(const void *a, const void *b)
+{
+    const struct ko *x = a, *y = b;
+    if (x->bucket != y->bucket) return x->bucket < y->bucket ? -1 : 1;
+    return x->id > y->id ? -1 : (x->id < y->id ? 1 : 0);     /* newest insertion first inside a bucket */
+}
+
+/* hashFirst/hashNext walk buckets 0..size-1, each bucket newest-first (hashAddN prepends, cuskent/hash.c:131-133);
+ * the table doubles whenever elCount > size after an add (hash.c:136-140) and hashResize keeps the in-bucket
+ * order (hash.c:389-409). The final order therefore depends only on the final size. */
+void names_kent_order(const names_t *t, int start_pow2, uint32_t *order)
+{
+    uint64_t size = 1ull << start_pow2;
+    for (uint64_t n = 1; n <= t->n; n++)
+        if (n > size) size *= 2;
+    struct ko *k = xmalloc(sizeof *k * (t->n ? t->n : 1));
+    for (uint32_t i = 0; i < t->n; i++) {
+        k[i].bucket = kent_hash_string(t->name[i]) & (uint32_t)(size - 1);
+        k[i].id = i;
+    }
+    qsort(k, t->n, sizeof *k, ko_cmp);
+    for (uint32_t i = 0; i < t->n; i++) order[i] = k[i].id;
+    free(k);
+}
+
+/* ------------------------------------------------------------------------------------- line reading */
+typedef struct {
+    FILE *f;
+    int is_pipe;
+    char *buf;
+    size_t cap;
+    int line_ix;
+    const char *name;
+} lines_t;
+
+static int ends_with(const char *s, const char *suf)
+{
+    size_t a = strlen(s), b = strlen(suf);
+    return a >= b && strcmp(s + a - b, suf) == 0;
+}
+
+/* generic.c:43-51 lineFileOpen2 + cuskent/linefile.c:34-60 (compressed inputs go through a decompressor pipe) */
+static void lines_open(lines_t *l, const char *path)
+{
+    struct stat sb;
+    memset(l, 0, sizeof *l);
+    l->name = path;
+    if (stat(path, &sb) == 0 && S_ISDIR(sb.st_mode)) die("Error: %s is a directory not a file", path);
+    const char *prog = NULL;
+    if (ends_with(path, ".gz") || ends_with(path, ".Z")) prog = "gzip -dc";
+    else if (ends_with(path, ".bz2")) prog = "bzip2 -dc";
+    else if (ends_with(path, ".zip")) prog = "unzip -p";
+    if (prog) {
+        if (access(path, R_OK) != 0) die("Couldn't open %s , %s", path, strerror(errno));
+        size_t n = strlen(prog) + strlen(path) + 8;
+        char *cmd = xmalloc(n);
+        snprintf(cmd, n, "%s '%s'", prog, path);
+        l->f = popen(cmd, "r");
+        free(cmd);
+        l->is_pipe = 1;
+    } else {
+        l->f = fopen(path, "r");
+    }
+    if (!l->f) die("Couldn't open %s , %s", path, strerror(errno));
+}
+
+/* next non-blank line that does not start with '#', chopped on white space (cuskent/linefile.c:855-870,
+ * common.c:1915-1953): returns the number of words (at most max), 0 at end of file */
+static int lines_next_words(lines_t *l, char **w, int max)
+{
+    ssize_t len;
+    while ((len = getline(&l->buf, &l->cap, l->f)) >= 0) {
+        l->line_ix++;
+        char *p = l->buf;
+        if (p[0] == '#') continue;
+        int n = 0;
+        for (;;) {
+            if (n >= max) break;
+            while (isspace((unsigned char)*p)) ++p;
+            if (*p == 0) break;
+            w[n++] = p;
+            while (*p && !isspace((unsigned char)*p)) ++p;
+            if (*p == 0) break;
+            *p++ = 0;
+        }
+        if (n) return n;
+    }
+    return 0;
+}
+
+static void lines_close(lines_t *l)
+{
+    if (l->f) {
+        if (l->is_pipe) pclose(l->f); else fclose(l->f);
+    }
+    free(l->buf);
+    memset(l, 0, sizeof *l);
+}
+
+/* -------------------------------------------------------------------------------------------- sizes */
+void sizes_load(const char *path, sizes_t *out)
+{
+    lines_t l;
+    char *w[2];
+    int n;
+    names_init(&out->names);
+    out->value = NULL;
+    size_t cap = 0;
+    /* hashNameIntFile uses lineFileOpen (no directory check message of its own) */
+    lines_open(&l, path);
+    while ((n = lines_next_words(&l, w, 2)) != 0) {
+        if (n < 2) die("Expecting %d words line %d of %s got %d", 2, l.line_ix, path, n);
+        if (w[1][0] != '-' && !isdigit((unsigned char)w[1][0]))
+            die("Expecting number field %d line %d of %s, got %s", 2, l.line_ix, path, w[1]);
+        uint32_t id = names_intern(&out->names, w[0]);     /* a repeated name keeps its id; the later value wins */
+        if (id >= cap) {
+            cap = cap ? cap * 2 : 256;
+            if (cap <= id) cap = id + 1;
+            out->value = xrealloc(out->value, sizeof(int64_t) * cap);
+        }
+        out->value[id] = atoi(w[1]);
+    }
+    lines_close(&l);
+}
+
+void sizes_free(sizes_t *s)
+{
+    names_free(&s->names);
+    free(s->value);
+    s->value = NULL;
+}
+
+int64_t sizes_get(const sizes_t *s, const char *name, int64_t dflt)
+{
+    int64_t i = names_find(&s->names, name);
+    return i < 0 ? dflt : s->value[i];
+}
+
+/* --------------------------------------------------------------------------------------------- rmsk */
+#define GROW(ptr, n, cap, type)                                   \
+    do {                                                          \
+        if ((n) >= (cap)) {                                       \
+            (cap) = (cap) ? (cap) * 2 : 1024;                     \
+            (ptr) = xrealloc((ptr), sizeof(type) * (cap));        \
+        }                                                         \
+    } while (0)
+
+void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_sizes, int filter_field, const char *filter_name,
+               rmsk_t *r)
+{
+    lines_t l;
+    char *w[17];
+    int n;
+    memset(r, 0, sizeof *r);
+    names_init(&r->chroms);
+    names_init(&r->reps);
+    names_init(&r->fams);
+    names_init(&r->clas);
+    size_t cap_rows = 0, cap_chr = 0, cap_rep = 0, cap_fam = 0, cap_cla = 0;
+    lines_open(&l, path);
+    while ((n = lines_next_words(&l, w, 17)) != 0) {
+        if (n < 17) die("Expecting %d words line %d of %s got %d", 17, l.line_ix, path, n);
+        if (filter_field != 0 && strcmp(filter_name, w[filter_field]) != 0) continue;      /* generic.c:1588-1591 */
+        r->repeat_num++;
+        /* generic.c:1594-1607: (unsigned int)strtol(..., 0) */
+        const char strand = w[9][0];
+        itx_row row;
+        row.cons_start = (uint32_t)strtol(strand == '+' ? w[13] : w[15], NULL, 0);
+        row.cons_end = (uint32_t)strtol(w[14], NULL, 0);
+        row.start = (uint32_t)strtol(w[6], NULL, 0);
+        row.end = (uint32_t)strtol(w[7], NULL, 0);
+        const uint32_t length = row.end - row.start;
+        /* generic.c:1613-1626: first row of a chromosome creates its binKeeper if the size file knows it */
+        int64_t ci = names_find(&r->chroms, w[5]);
+        if (ci < 0) {
+            const int size = (int)sizes_get(chr_sizes, w[5], 0);
+            if (size == 0) continue;                                                        /* freermsk + continue */
+            if (size < 0) die("bad range %d,%d in binKeeperNew", 0, size);                  /* cuskent/binRange.c:145-146 */
+            ci = names_intern(&r->chroms, w[5]);
+            GROW(r->chrom_size, (size_t)ci, cap_chr, int64_t);
+            r->chrom_size[ci] = size;
+        }
+        /* binKeeperAdd's range check (cuskent/binRange.c:176-178); itx_table_create repeats it for the whole table */
+        {
+            const int s = (int)row.start, e = (int)row.end, mx = (int)r->chrom_size[ci];
+            if (s < 0 || e > mx || s > e) die("(%d %d) out of range (%d %d) in binKeeperAdd", s, e, 0, mx);
+        }
+        row.chrom = (int32_t)names_find(&chr_sizes->names, w[5]);      /* the engine indexes chromosomes as the size file does */
+        row.rep = row.fam = row.cla = 0;
+        {   /* generic.c:1628-1693. With a name/class/family filter the reference leaves hashRep/hashFam/hashCla empty;
+             * the rows still carry their own strings (printed by writeFilterOut), so the ids are kept either way. */
+            const uint32_t before_rep = r->reps.n, before_fam = r->fams.n, before_cla = r->clas.n;
+            const uint32_t rep = names_intern(&r->reps, w[10]);
+            const uint32_t cla = names_intern(&r->clas, w[11]);
+            const uint32_t fam = names_intern(&r->fams, w[12]);
+            if (rep == before_rep) {
+                if (rep >= cap_rep) {
+                    cap_rep = cap_rep ? cap_rep * 2 : 1024;
+                    r->rep_len = xrealloc(r->rep_len, sizeof(uint32_t) * cap_rep);
+                    r->rep_fam = xrealloc(r->rep_fam, sizeof(uint32_t) * cap_rep);
+                    r->rep_cla = xrealloc(r->rep_cla, sizeof(uint32_t) * cap_rep);
+                    r->rep_genome = xrealloc(r->rep_genome, sizeof(uint64_t) * cap_rep);
+                    r->rep_total = xrealloc(r->rep_total, sizeof(uint64_t) * cap_rep);
+                }
+                r->rep_len[rep] = (uint32_t)(int)sizes_get(rep_sizes, w[10], 0);
+                r->rep_fam[rep] = fam;
+                r->rep_cla[rep] = cla;
+                r->rep_genome[rep] = 0;
+                r->rep_total[rep] = 0;
+            }
+            if (fam == before_fam) {
+                if (fam >= cap_fam) {
+                    cap_fam = cap_fam ? cap_fam * 2 : 256;
+                    r->fam_cla = xrealloc(r->fam_cla, sizeof(uint32_t) * cap_fam);
+                    r->fam_genome = xrealloc(r->fam_genome, sizeof(uint64_t) * cap_fam);
+                    r->fam_total = xrealloc(r->fam_total, sizeof(uint64_t) * cap_fam);
+                }
+                r->fam_cla[fam] = cla;
+                r->fam_genome[fam] = 0;
+                r->fam_total[fam] = 0;
+            }
+            if (cla == before_cla) {
+                if (cla >= cap_cla) {
+                    cap_cla = cap_cla ? cap_cla * 2 : 64;
+                    r->cla_genome = xrealloc(r->cla_genome, sizeof(uint64_t) * cap_cla);
+                    r->cla_total = xrealloc(r->cla_total, sizeof(uint64_t) * cap_cla);
+                }
+                r->cla_genome[cla] = 0;
+                r->cla_total[cla] = 0;
+            }
+            r->rep_genome[rep]++;
+            r->rep_total[rep] += length;
+            r->fam_genome[fam]++;
+            r->fam_total[fam] += length;
+            r->cla_genome[cla]++;
+            r->cla_total[cla] += length;
+            row.rep = rep;
+            row.fam = fam;
+            row.cla = cla;
+        }
+        if (r->n_rows >= cap_rows) {
+            cap_rows = cap_rows ? cap_rows * 2 : 4096;
+            r->rows = xrealloc(r->rows, sizeof(itx_row) * cap_rows);
+            r->row_chrom_name = xrealloc(r->row_chrom_name, sizeof(uint32_t) * cap_rows);
+        }
+        r->rows[r->n_rows] = row;
+        r->row_chrom_name[r->n_rows] = (uint32_t)ci;
+        r->n_rows++;
+    }
+    lines_close(&l);
+}
+
+void rmsk_free(rmsk_t *r)
+{
+    names_free(&r->chroms);
+    names_free(&r->reps);
+    names_free(&r->fams);
+    names_free(&r->clas);
+    free(r->rows);
+    free(r->row_chrom_name);
+    free(r->chrom_size);
+    free(r->rep_len);
+    free(r->rep_fam);
+    free(r->rep_cla);
+    free(r->fam_cla);
+    free(r->rep_genome);
+    free(r->rep_total);
+    free(r->fam_genome);
+    free(r->fam_total);
+    free(r->cla_genome);
+    free(r->cla_total);
+    memset(r, 0, sizeof *r);
+}
+
+char *filename_without_ext(const char *path)
+{
+    char *s = xstrdup(path);
+    char *dot = strrchr(s, '.');
+    if (!dot || dot == s) return s;
+    *dot = '\0';
+    return s;
+}

@@ -13,6 +13,8 @@
 
 #define BGZF_MAX 0x10000
 
+static uint32_t rd_u32_at(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
 struct aln_reader {
     FILE *f;
     int is_sam;
@@ -20,13 +22,16 @@ struct aln_reader {
     int n_targets;
     char **tname;
     names_t tnames;
-    /* BGZF state */
-    uint8_t *cbuf, *ubuf;
-    size_t ulen, upos;
-    int eof;
-    /* record scratch */
-    uint8_t *rec;
-    size_t rec_cap;
+    /* BGZF state: the file is consumed in chunks of many blocks; the blocks of a chunk are inflated in parallel
+     * (they are independent gzip members), then records are located by one sequential hop over the block_len
+     * fields and parsed in parallel straight into the staging SoA */
+    uint8_t *cbuf;            /* compressed bytes of the current chunk (+ the incomplete block carried over)   */
+    size_t clen, ccap;
+    uint8_t *ubuf;            /* inflated bytes: unconsumed tail of the previous chunk + this chunk            */
+    size_t ulen, upos, ucap;
+    size_t *rec_off;          /* start of every complete record in ubuf                                        */
+    size_t n_rec, rec_next, rec_cap;
+    int eof;                  /* no more compressed input (end of file or a damaged block)                     */
     /* SAM state */
     char *line;
     size_t line_cap;
@@ -35,64 +40,127 @@ struct aln_reader {
 };
 
 /* ---- BGZF ------------------------------------------------------------------------------------------------ */
-static int bgzf_next_block(aln_reader *r)
+#define CHUNK_COMPRESSED (48u << 20)
+
+struct blk {
+    size_t coff, csize, uoff, usize;
+};
+
+/* bgzf.c:401-411 check_header: gzip member with exactly one 6-byte extra field "BC" */
+static int bgzf_header_ok(const uint8_t *h)
 {
-    uint8_t hdr[18];
-    for (;;) {
-        size_t got = fread(hdr, 1, 18, r->f);
-        if (got == 0) {
-            r->eof = 1;
-            return 0;
-        }
-        /* bgzf.c:401-411 check_header: gzip member with exactly one 6-byte extra field "BC" */
-        if (got != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4) || (hdr[10] | hdr[11] << 8) != 6 ||
-            hdr[12] != 'B' || hdr[13] != 'C' || (hdr[14] | hdr[15] << 8) != 2) {
-            r->eof = 1;
-            return -1;
-        }
-        const size_t bsize = (size_t)(hdr[16] | hdr[17] << 8) + 1;
-        if (bsize < 26) {
-            r->eof = 1;
-            return -1;
-        }
-        const size_t rest = bsize - 18;
-        if (fread(r->cbuf, 1, rest, r->f) != rest) {
-            r->eof = 1;
-            return -1;
-        }
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        zs.next_in = r->cbuf;
-        zs.avail_in = (uInt)(rest - 8);
-        zs.next_out = r->ubuf;
-        zs.avail_out = BGZF_MAX;
-        if (inflateInit2(&zs, -15) != Z_OK) return -1;
-        const int rc = inflate(&zs, Z_FINISH);
-        inflateEnd(&zs);
-        if (rc != Z_STREAM_END) {
-            r->eof = 1;
-            return -1;
-        }
-        r->ulen = zs.total_out;
-        r->upos = 0;
-        if (r->ulen) return 1;       /* empty blocks (the EOF marker) are skipped */
-    }
+    return h[0] == 31 && h[1] == 139 && h[2] == 8 && (h[3] & 4) && (h[10] | h[11] << 8) == 6 && h[12] == 'B' && h[13] == 'C' &&
+           (h[14] | h[15] << 8) == 2;
 }
 
+static int inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t usize)
+{
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    zs.next_in = (Bytef *)(src + 18);
+    zs.avail_in = (uInt)(csize - 18 - 8);
+    zs.next_out = dst;
+    zs.avail_out = (uInt)usize;
+    if (inflateInit2(&zs, -15) != Z_OK) return -1;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return (rc == Z_STREAM_END && zs.total_out == usize) ? 0 : -1;
+}
+
+/* Reads the next chunk of compressed blocks, inflates them in parallel behind the unconsumed bytes of ubuf.
+ * Returns the number of bytes added (0 at end of input). */
+static size_t bgzf_load_chunk(aln_reader *r)
+{
+    if (r->eof) return 0;
+    /* keep what the record parser has not consumed */
+    if (r->upos) {
+        memmove(r->ubuf, r->ubuf + r->upos, r->ulen - r->upos);
+        r->ulen -= r->upos;
+        r->upos = 0;
+    }
+    if (r->ccap < CHUNK_COMPRESSED + BGZF_MAX + 64) {
+        r->ccap = CHUNK_COMPRESSED + BGZF_MAX + 64;
+        r->cbuf = xrealloc(r->cbuf, r->ccap);
+    }
+    const size_t got = fread(r->cbuf + r->clen, 1, r->ccap - r->clen, r->f);
+    r->clen += got;
+    if (r->clen == 0) {
+        r->eof = 1;
+        return 0;
+    }
+    /* index the complete blocks */
+    static __thread struct blk *bl = NULL;
+    static __thread size_t bl_cap = 0;
+    size_t nb = 0, off = 0, utot = 0;
+    int damaged = 0;
+    while (off + 18 <= r->clen) {
+        const uint8_t *h = r->cbuf + off;
+        if (!bgzf_header_ok(h)) {
+            damaged = 1;
+            break;
+        }
+        const size_t bsize = (size_t)(h[16] | h[17] << 8) + 1;
+        if (bsize < 26) {
+            damaged = 1;
+            break;
+        }
+        if (off + bsize > r->clen) break;                      /* incomplete: wait for more input */
+        const size_t usize = rd_u32_at(h + bsize - 4);
+        if (usize > BGZF_MAX) {
+            damaged = 1;
+            break;
+        }
+        if (nb == bl_cap) {
+            bl_cap = bl_cap ? bl_cap * 2 : 4096;
+            bl = xrealloc(bl, sizeof *bl * bl_cap);
+        }
+        bl[nb].coff = off;
+        bl[nb].csize = bsize;
+        bl[nb].uoff = utot;
+        bl[nb].usize = usize;
+        nb++;
+        utot += usize;
+        off += bsize;
+    }
+    if (r->ulen + utot + 64 > r->ucap) {
+        r->ucap = (r->ulen + utot) * 5 / 4 + BGZF_MAX + 64;
+        r->ubuf = xrealloc(r->ubuf, r->ucap);
+    }
+    int bad = 0;
+    uint8_t *dst0 = r->ubuf + r->ulen;
+#pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
+    for (long i = 0; i < (long)nb; i++)
+        if (bl[i].usize && inflate_block(r->cbuf + bl[i].coff, bl[i].csize, dst0 + bl[i].uoff, bl[i].usize) != 0) bad |= 1;
+    if (bad) {
+        /* a block that does not inflate ends the stream there, like bgzf_read returning an error (bgzf.c:471-521) */
+        size_t ok = 0;
+        for (size_t i = 0; i < nb; i++) {
+            if (bl[i].usize && inflate_block(r->cbuf + bl[i].coff, bl[i].csize, dst0 + bl[i].uoff, bl[i].usize) != 0) break;
+            ok = bl[i].uoff + bl[i].usize;
+        }
+        utot = ok;
+        damaged = 1;
+    }
+    r->ulen += utot;
+    /* carry the incomplete tail block over */
+    memmove(r->cbuf, r->cbuf + off, r->clen - off);
+    r->clen -= off;
+    if (damaged || (got == 0 && nb == 0)) r->eof = 1;
+    if (got == 0 && r->clen > 0 && nb == 0) r->eof = 1;       /* truncated last block */
+    return utot;
+}
+
+/* sequential read of n bytes (header parsing) */
 static size_t bgzf_read(aln_reader *r, void *dst, size_t n)
 {
-    size_t done = 0;
-    while (done < n) {
-        if (r->upos == r->ulen) {
-            if (r->eof || bgzf_next_block(r) <= 0) break;
-        }
-        size_t k = r->ulen - r->upos;
-        if (k > n - done) k = n - done;
-        memcpy((uint8_t *)dst + done, r->ubuf + r->upos, k);
-        r->upos += k;
-        done += k;
+    while (r->ulen - r->upos < n) {
+        if (bgzf_load_chunk(r) == 0 && r->eof) break;
     }
-    return done;
+    size_t k = r->ulen - r->upos;
+    if (k > n) k = n;
+    memcpy(dst, r->ubuf + r->upos, k);
+    r->upos += k;
+    return k;
 }
 
 static int32_t rd_i32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
@@ -178,8 +246,6 @@ aln_reader *aln_open(const char *path, int is_sam)
     if (is_sam) {
         rc = sam_read_header(r);
     } else {
-        r->cbuf = xmalloc(BGZF_MAX + 64);
-        r->ubuf = xmalloc(BGZF_MAX + 64);
         rc = bam_read_header(r);
     }
     if (rc != 0) {
@@ -199,7 +265,7 @@ void aln_close(aln_reader *r)
     names_free(&r->tnames);
     free(r->cbuf);
     free(r->ubuf);
-    free(r->rec);
+    free(r->rec_off);
     free(r->line);
     free(r);
 }
@@ -234,51 +300,89 @@ static int aux_has_tag(const uint8_t *s, const uint8_t *end, char t0, char t1)
     return 0;
 }
 
+/* bam.c:179-210 for one record that is completely in memory */
+static inline void bam_parse_one(const uint8_t *p, size_t n, itx_staging *st, char **qnames, int *any_paired, int *aux_xa)
+{
+    const int32_t block_len = rd_i32(p);
+    const uint8_t *core = p + 4, *data = p + 36;
+    const size_t dlen = (size_t)block_len - 32;
+    const int32_t tid = rd_i32(core), pos = rd_i32(core + 4);
+    const uint32_t x1 = rd_u32(core + 8), x2 = rd_u32(core + 12);
+    const uint32_t l_qname = x1 & 0xff, qual = (x1 >> 8) & 0xff, flag = x2 >> 16, n_cigar = x2 & 0xffff;
+    const int32_t l_qseq = rd_i32(core + 16), mpos = rd_i32(core + 24), isize = rd_i32(core + 28);
+    int32_t tmpend;
+    if (n_cigar && (size_t)l_qname + 4 * (size_t)n_cigar <= dlen) {
+        uint32_t e = (uint32_t)pos;                               /* bam.c:17-27 */
+        const uint8_t *cg = data + l_qname;
+        for (uint32_t k = 0; k < n_cigar; k++) {
+            const uint32_t c = rd_u32(cg + 4 * k), op = c & 0xf;
+            if (op == 0 || op == 2 || op == 3) e += c >> 4;       /* M, D, N */
+        }
+        tmpend = (int32_t)e;
+    } else {
+        tmpend = (int32_t)((uint32_t)pos + (uint32_t)l_qseq);     /* generic.c:820 */
+    }
+    st->tid[n] = tid;
+    st->pos[n] = pos;
+    st->tmpend[n] = tmpend;
+    st->mapq[n] = (uint8_t)qual;
+    st->flag5[n] = ITX_FLAG5(flag);
+    st->mpos[n] = mpos;
+    st->isize[n] = isize;
+    if (flag & 1) *any_paired = 1;
+    if (qnames) qnames[n] = xstrdup(l_qname && l_qname <= dlen ? (const char *)data : "");
+    const size_t ql = l_qseq > 0 ? (size_t)l_qseq : 0;
+    const size_t off = (size_t)l_qname + 4 * (size_t)n_cigar + (ql + 1) / 2 + ql;
+    if (off < dlen && aux_has_tag(data + off, data + dlen, 'X', 'A')) *aux_xa = 1;
+}
+
 static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa)
 {
     size_t n = 0;
-    uint8_t b4[4], core[32];
     while (n < cap) {
-        if (bgzf_read(r, b4, 4) != 4) break;                         /* bam.c:186-187 */
-        const int32_t block_len = rd_i32(b4);
-        if (block_len < 32) break;
-        if (bgzf_read(r, core, 32) != 32) break;                     /* bam.c:190 */
-        const size_t dlen = (size_t)block_len - 32;
-        if (dlen > r->rec_cap) {
-            r->rec_cap = dlen * 2 + 256;
-            r->rec = xrealloc(r->rec, r->rec_cap);
-        }
-        if (bgzf_read(r, r->rec, dlen) != dlen) break;               /* bam.c:205 */
-        const int32_t tid = rd_i32(core), pos = rd_i32(core + 4);
-        const uint32_t x1 = rd_u32(core + 8), x2 = rd_u32(core + 12);
-        const uint32_t l_qname = x1 & 0xff, qual = (x1 >> 8) & 0xff, flag = x2 >> 16, n_cigar = x2 & 0xffff;
-        const int32_t l_qseq = rd_i32(core + 16), mpos = rd_i32(core + 24), isize = rd_i32(core + 28);
-        int32_t tmpend;
-        if (n_cigar && (size_t)l_qname + 4 * (size_t)n_cigar <= dlen) {
-            uint32_t e = (uint32_t)pos;                               /* bam.c:17-27 */
-            const uint8_t *cg = r->rec + l_qname;
-            for (uint32_t k = 0; k < n_cigar; k++) {
-                const uint32_t c = rd_u32(cg + 4 * k), op = c & 0xf;
-                if (op == 0 || op == 2 || op == 3) e += c >> 4;       /* M, D, N */
+        if (r->rec_next == r->n_rec) {
+            /* locate the records of what is inflated; load more when none is complete */
+            r->n_rec = r->rec_next = 0;
+            for (;;) {
+                size_t p = r->upos;
+                while (p + 4 <= r->ulen) {
+                    const int32_t bl = rd_i32(r->ubuf + p);
+                    if (bl < 32) {                                /* bam.c:186-190: a malformed length ends the file */
+                        r->eof = 1;
+                        r->ulen = p;
+                        break;
+                    }
+                    if (p + 4 + (size_t)bl > r->ulen) break;
+                    if (r->n_rec == r->rec_cap) {
+                        r->rec_cap = r->rec_cap ? r->rec_cap * 2 : 1 << 20;
+                        r->rec_off = xrealloc(r->rec_off, sizeof(size_t) * r->rec_cap);
+                    }
+                    r->rec_off[r->n_rec++] = p;
+                    p += 4 + (size_t)bl;
+                }
+                if (r->n_rec) {
+                    r->upos = p;                                  /* consumed up to here once these are parsed */
+                    break;
+                }
+                if (bgzf_load_chunk(r) == 0 && r->eof) break;     /* end of input (a truncated tail record is dropped) */
             }
-            tmpend = (int32_t)e;
-        } else {
-            tmpend = (int32_t)((uint32_t)pos + (uint32_t)l_qseq);     /* generic.c:820 */
+            if (r->n_rec == 0) break;
         }
-        st->tid[n] = tid;
-        st->pos[n] = pos;
-        st->tmpend[n] = tmpend;
-        st->mapq[n] = (uint8_t)qual;
-        st->flag5[n] = ITX_FLAG5(flag);
-        st->mpos[n] = mpos;
-        st->isize[n] = isize;
-        if (flag & 1) *any_paired = 1;
-        if (qnames) qnames[n] = xstrdup(l_qname && l_qname <= dlen ? (const char *)r->rec : "");
-        if (!*aux_xa) {
-            const size_t off = (size_t)l_qname + 4 * (size_t)n_cigar + ((size_t)(l_qseq > 0 ? l_qseq : 0) + 1) / 2 + (size_t)(l_qseq > 0 ? l_qseq : 0);
-            if (off < dlen && aux_has_tag(r->rec + off, r->rec + dlen, 'X', 'A')) *aux_xa = 1;
+        size_t m = r->n_rec - r->rec_next;
+        if (m > cap - n) m = cap - n;
+        const size_t *ro = r->rec_off + r->rec_next;
+        int ap = 0, xa = 0;
+#pragma omp parallel for schedule(static) reduction(| : ap, xa)
+        for (long i = 0; i < (long)m; i++) {
+            int a1 = 0, x1 = 0;
+            bam_parse_one(r->ubuf + ro[i], n + (size_t)i, st, qnames, &a1, &x1);
+            ap |= a1;
+            xa |= x1;
         }
-        n++;
+        if (ap) *any_paired = 1;
+        if (xa) *aux_xa = 1;
+        r->rec_next += m;
+        n += m;
     }
     return n;
 }

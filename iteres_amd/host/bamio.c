@@ -128,9 +128,11 @@ static size_t bgzf_load_chunk(aln_reader *r)
     }
     int bad = 0;
     uint8_t *dst0 = r->ubuf + r->ulen;
+    const struct blk *blocks = bl;                             /* the thread-local pointer, shared with the workers */
+    const uint8_t *cbase = r->cbuf;
 #pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
     for (long i = 0; i < (long)nb; i++)
-        if (bl[i].usize && inflate_block(r->cbuf + bl[i].coff, bl[i].csize, dst0 + bl[i].uoff, bl[i].usize) != 0) bad |= 1;
+        if (blocks[i].usize && inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
     if (bad) {
         /* a block that does not inflate ends the stream there, like bgzf_read returning an error (bgzf.c:471-521) */
         size_t ok = 0;

@@ -1,0 +1,87 @@
+"""Host logic on CPU: the product's alignment decoder (iteres_amd/host/bamio.c: parallel BGZF inflate + record parse,
+SAM text) against the independent Python readers of tests/refio.py, field by field, on every golden alignment file
+and on stress files (many small BGZF blocks, records spanning blocks, odd batch sizes, truncation)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import goldencase as gc
+import refio
+from iteres_amd import engine as eng, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "iteres_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def dump(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bin") / "reader_dump")
+    subprocess.check_call(["gcc", "-O2", "-g", "-fopenmp", "-std=gnu11", "-o", exe, os.path.join(HOST, "test", "reader_dump.c"),
+                           os.path.join(HOST, "bamio.c"), os.path.join(HOST, "tables.c"), "-lz"])
+    return exe
+
+
+def run_dump(exe, path, is_sam, batch=4096, threads=4):
+    pr = subprocess.run([exe, path, str(int(is_sam)), str(batch)], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+    assert pr.returncode == 0, pr.stderr
+    hdr, recs, tail = [], [], None
+    for line in pr.stdout.split("\n"):
+        if line.startswith("@"):
+            hdr.append(line.split("\t")[1])
+        elif line.startswith("#"):
+            tail = line
+        elif line:
+            recs.append(line.split("\t"))
+    return hdr, recs, tail, pr.stderr
+
+
+def check(hdr, recs, header, rd):
+    assert hdr == [n for n, _ in header]
+    assert len(recs) == len(rd["tid"])
+    f5 = eng.flag5(rd["flag"])
+    for i, r in enumerate(recs):
+        want = [int(rd["tid"][i]), int(rd["pos"][i]), int(rd["tmpend"][i]), int(rd["mapq"][i]), int(f5[i]), int(rd["mpos"][i]), int(rd["isize"][i])]
+        assert [int(x) for x in r[:7]] == want, (i, r, want)
+        assert r[7] == rd["qname"][i]
+
+
+@pytest.mark.parametrize("case", ["quirks", "mid", "cfg1_chr22", "manynames"])
+def test_golden_alignment_files(case, dump, tmp_path):
+    src = os.path.join(gc.GOLDEN, case, "in")
+    for name in ("reads.bam", "reads.sam"):
+        if not (os.path.exists(os.path.join(src, name)) or os.path.exists(os.path.join(src, name + ".gz"))):
+            continue
+        path = refio.materialise(src, name, str(tmp_path))
+        header, rd = gc.load_reads(case, name)
+        for batch in (4096, 777):
+            hdr, recs, tail, _ = run_dump(dump, path, name.endswith(".sam"), batch)
+            check(hdr, recs, header, rd)
+        assert f"paired={int(bool((rd['flag'] & 1).any()))}" in tail
+
+
+def test_many_small_blocks_and_truncation(dump, tmp_path):
+    chroms = [("c1", 5_000_000), ("c2", 900_000)]
+    r = synth.make_reads(77, chroms, 30_000, read_len=(30, 90), paired_frac=0.3, odd_cigar_frac=0.2)
+    r.aux = [["NM:i:1", "XA:Z:c1,+100,30M,1;"] if i == 12345 else [] for i in range(len(r))]
+    path = str(tmp_path / "small.bam")
+    synth.write_bam(path, r, with_seq=True, block=700)             # thousands of tiny blocks: every record spans blocks
+    header, rd = refio.read_bam(path)
+    for threads in (1, 5):
+        hdr, recs, tail, _ = run_dump(dump, path, False, batch=9999, threads=threads)
+        check(hdr, recs, header, rd)
+        assert "xa=1" in tail
+    # truncated in the middle of a block: a clean prefix of the records, no crash
+    data = open(path, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(data[: len(data) * 2 // 3 + 11])
+    hdr, recs, tail, _ = run_dump(dump, cut, False, batch=4096)
+    assert 0 < len(recs) < len(rd["tid"])
+    for i in (0, len(recs) // 2, len(recs) - 1):
+        assert int(recs[i][1]) == int(rd["pos"][i]) and recs[i][7] == rd["qname"][i]
+    # not a BAM at all
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(b"this is not a bam file" * 10)
+    pr = subprocess.run([dump, bad, "0"], capture_output=True, text=True)
+    assert pr.returncode == 1

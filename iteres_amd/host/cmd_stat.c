@@ -37,6 +37,14 @@ static int stat_usage(void)
     return 1;
 }
 
+/* ITX_TIMING=1: phase wall times on stderr (not part of the reference's output) */
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static char *fmt_name(const char *prefix, const char *suffix)
 {
     char *s = NULL;
@@ -119,6 +127,8 @@ int main_stat(int argc, char **argv)
     if (o.dedup) die("-R (remove redundant reads, generic.c:907-919) is not built into this version");
     if (optBed || optBedUniq) die("-B / -V (bed output, generic.c:925-936) is not built into this version");
 
+    const int timing = getenv("ITX_TIMING") != NULL;
+    const double t_begin = now_s();
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);
@@ -127,11 +137,13 @@ int main_stat(int argc, char **argv)
     rmsk_load(o.rmsk_file, &chr_sizes, &rep_sizes, 0, "ALL", &rm);
     fprintf(stderr, "* Total %d repeats found.\n", rm.repeat_num);
 
+    const double t_loaded = now_s();
     fprintf(stderr, "* Parsing the SAM/BAM file\n");
     itx_engine *eng = NULL;
     itx_table *tab = NULL;
     run_stream(&o, &rm, &chr_sizes, 0, 1, 100000, 0, &eng, &tab, NULL);
 
+    const double t_streamed = now_s();
     fprintf(stderr, "* Writing stats and Wig file\n");
     itx_table_info info;
     if (itx_table_get_info(tab, &info) != ITX_OK) die("itx_table_get_info: %s", itx_last_error());
@@ -158,6 +170,9 @@ int main_stat(int argc, char **argv)
     fprintf(stderr, "* Preparing report file\n");
     write_report(outReport, cnt, o.mapq, "ALL");
 
+    if (timing)
+        fprintf(stderr, "[itx timing] load %.3f s, table+scan %.3f s, finish+write %.3f s\n", t_loaded - t_begin, t_streamed - t_loaded,
+                now_s() - t_streamed);
     itx_engine_destroy(eng);
     itx_table_destroy(tab);
     rmsk_free(&rm);

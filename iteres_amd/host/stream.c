@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <time.h>
 
 #define BATCH_RECORDS (4u << 20)
 
@@ -37,6 +38,9 @@ typedef struct {
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
                 unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names)
 {
+    const int timing = getenv("ITX_TIMING") != NULL;
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     int ndev = itx_device_count();
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
     /* table: every chromosome of the size file is known to the engine (a read may land on one without repeats) */
@@ -62,6 +66,8 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     p.accum = ITX_ACCUM_DEFAULT;
     itx_engine *eng = NULL;
     chk(itx_engine_create(tab, &p, BATCH_RECORDS, &eng), "itx_engine_create");
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    if (timing) fprintf(stderr, "[itx timing] table build + engine %.3f s\n", (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec));
     itx_staging st[2];
     chk(itx_engine_staging(eng, 0, &st[0]), "itx_engine_staging");
     chk(itx_engine_staging(eng, 1, &st[1]), "itx_engine_staging");

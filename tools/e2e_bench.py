@@ -37,7 +37,7 @@ def main():
     synth.write_sizes(os.path.join(tmp, "chrom.sizes"), chroms)
     synth.write_sizes(os.path.join(tmp, "rep.sizes"), tb.rep_len.items())
     synth.write_rmsk(os.path.join(tmp, "rmsk.txt"), tb)
-    env = dict(os.environ, OMP_NUM_THREADS=threads)
+    env = dict(os.environ, OMP_NUM_THREADS=threads, ITX_TIMING="1")
     subprocess.check_call([mk, os.path.join(tmp, "chrom.sizes"), str(n_reads), os.path.join(tmp, "reads.bam"), str(seq_len), "7"], env=env)
     same_bam = ref_reads == n_reads
     if not same_bam:
@@ -57,6 +57,9 @@ def main():
         out[name] = {"rc": pr.returncode, "reads": nr, "wall_s": round(dt, 2), "M_reads_per_s_whole_command": round(nr / dt / 1e6, 3)}
         if pr.returncode != 0:
             out[name]["stderr_tail"] = pr.stderr[-400:]
+        tl = [l for l in pr.stderr.split("\n") if l.startswith("[itx timing]")]
+        if tl:
+            out[name]["phases"] = tl
     if "reference" in out and same_bam:
         same = {}
         for fn in sorted(os.listdir(os.path.join(tmp, "reference"))):

@@ -11,7 +11,8 @@
 struct __attribute__((aligned(16))) ItxIv {
     // first 16 bytes: all the overlap scan reads
     int32_t  s, e;        // genomic [s, e)
-    int32_t  pmax_e;      // max e over this chromosome's intervals [first .. this]: scan-stop bound
+    int32_t  pbelow;      // max e over this chromosome's intervals BELOW this one (INT32_MIN for the first): a scan that
+                          // walks down from here goes on only while pbelow > query start
     uint32_t rank;        // position in binKeeperFind's list order within the chromosome (binRange.c:209-225)
     // second 16 bytes: read once, for the chosen row
     uint32_t cs;          // consensus_start as the reference parses it (generic.c:1596-1600)
@@ -27,7 +28,7 @@ struct ItxDevTable {
     const int32_t  *orig;       // [n_rows] sorted index -> caller's row index
     const uint2    *bl;         // binned index, one slice per chromosome (ItxTidRec.bin_base), per bin b of 2^shift bp:
                                 //   .x = first index with s >= (b << shift)          (upper bound of "s < x" queries)
-                                //   .y = first index with pmax_e > (b << shift)      (lower bound of what can still overlap)
+                                //   .y = first index whose prefix-max end > (b << shift)      (lower bound of what can still overlap)
     int32_t  shift;
     uint32_t n_rows;
     uint32_t n_units;
@@ -101,12 +102,44 @@ void itx_set_error(const char *fmt, ...);
 struct ItxRunParams {
     uint32_t mapq_min;
     float    min_cov;
+    float    cov_hi, cov_lo;     // overlap >= qlen * cov_hi: certainly passes -c; overlap < qlen * cov_lo: certainly fails (itx_cov_bounds)
     uint32_t extension;
     uint32_t isize_max;
     int32_t  treat, discard, mode;
     int32_t  n_tid;
     const ItxTidRec *tidrec;    // device, [n_tid]
 };
+
+// The -c test of the reference is `fl32(overlap / qlen) < min_cov` (generic.c:296-301, 961-962). For overlaps and
+// lengths below 2^23 the kernels decide it with one multiply: overlap >= fl32(qlen * hi) implies the quotient
+// rounds to >= min_cov, overlap < fl32(qlen * lo) implies it rounds below; hi / lo sit 16 ulps either side of
+// min_cov (relative 2^-20, far beyond the 2^-24 roundings involved). Whatever falls between, and every min_cov
+// that is not a comfortably normal positive number, takes the exact division.
+static inline void itx_cov_bounds(float m, float *hi, float *lo)
+{
+    if (!(m > 0.0f)) {                      // zero, negative, NaN: `c < m` is never true, every hit passes
+        *hi = -__builtin_inff();
+        *lo = -__builtin_inff();
+        return;
+    }
+    if (__builtin_isinf(m)) {               // `c < inf` always true
+        *hi = __builtin_inff();
+        *lo = __builtin_inff();
+        return;
+    }
+    if (m < 1e-30f || m > 1e30f) {          // near the ends of the exponent range: always divide
+        *hi = __builtin_inff();
+        *lo = -__builtin_inff();
+        return;
+    }
+    float h = m, l = m;
+    for (int i = 0; i < 16; i++) {
+        h = __builtin_nextafterf(h, __builtin_inff());
+        l = __builtin_nextafterf(l, 0.0f);
+    }
+    *hi = h;
+    *lo = l;
+}
 
 struct ItxDevBatch {
     const int32_t *tid, *pos, *tmpend;

@@ -18,81 +18,7 @@ struct ItxRaw {
     uint32_t mapq, fl;
 };
 
-// What one record contributes to cnt[] (generic.c:1048-1060), as a bit set, plus its interval.
-// bit k set => cnt[k] += 1.  (cnt[8] and cnt[12] are never touched on the device; cnt[11] == cnt[7].)
-struct ItxDerived {
-    uint32_t cntbits;
-    uint32_t start, end;   // the reference's unsigned start/end
-    bool     ok;           // the record goes on to the lookup
-    bool     uniq;         // MAPQ >= -Q
-};
-
 __device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-
-// generic.c:748-922 for one record. tr = first 16 bytes of the record's ItxTidRec (chrom, size, iv_lo, iv_hi),
-// chrom = -1 when the tid is outside the header. i indexes mpos/isize (only read for paired records).
-__device__ __forceinline__ ItxDerived itx_derive(const ItxRunParams &P, const ItxDevBatch &B, const ItxRaw &r, const uint4 &tr, size_t i)
-{
-    ItxDerived d;
-    d.ok = false;
-    d.start = d.end = 0;
-    const uint32_t fl = r.fl;
-    d.uniq = r.mapq >= P.mapq_min;
-    // generic.c:748-759: which "read end" counter
-    const bool end1 = !(fl & F5_PAIRED) || (fl & F5_READ1) || P.treat;
-    d.cntbits = end1 ? 1u : 2u;
-    if (fl & F5_UNMAP) return d;                                  // generic.c:764
-    d.cntbits |= end1 ? (1u << 2) : (1u << 3);                   // generic.c:768-779
-    // generic.c:781-801; a tid outside the header crashes the reference, here it is "unknown chromosome"
-    if ((int32_t)tr.x < 0) return d;
-    const uint32_t cend = (uint32_t)((int32_t)tr.y - 1);         // generic.c:796
-    if (cend == 1u) return d;                                    // generic.c:797
-    d.cntbits |= end1 ? (1u << 4) : (1u << 5);                   // generic.c:802-813
-    bool se_style;
-    if (P.treat) {
-        se_style = true;
-    } else if (fl & F5_PAIRED) {
-        if (!(fl & F5_MUNMAP)) {
-            if (!(fl & F5_READ1)) return d;                      // generic.c:858-860
-            const int32_t isz = B.isize[i];
-            const uint32_t a = isz < 0 ? 0u - (uint32_t)isz : (uint32_t)isz;
-            if (a > P.isize_max || isz == 0) return d;           // generic.c:839-840
-            se_style = false;
-        } else {
-            if (P.discard) return d;                             // generic.c:862-863
-            se_style = true;
-        }
-    } else {
-        se_style = true;
-    }
-    d.cntbits |= (1u << 6);                                       // reads_mapped
-    if (d.uniq) d.cntbits |= (1u << 7);                           // reads_mapped_unique (== reads_nonredundant_unique without -R)
-    uint32_t start, end;
-    if (se_style) {                                               // generic.c:819-833
-        start = (uint32_t)r.pos;
-        end = umin32(cend, (uint32_t)r.tmpend);
-        if (P.extension) {
-            if (!(fl & F5_REVERSE)) {
-                end = umin32(start + P.extension, cend);
-            } else {
-                start = (end < P.extension) ? 0u : end - P.extension;
-            }
-        }
-    } else {                                                      // generic.c:845-855
-        const int32_t isz = B.isize[i];
-        if (isz > 0) {
-            start = (uint32_t)r.pos;
-            end = umin32(cend, start + (uint32_t)isz);
-        } else {
-            start = (uint32_t)B.mpos[i];
-            end = umin32(cend, start - (uint32_t)isz);
-        }
-    }
-    d.start = start;
-    d.end = end;
-    d.ok = true;
-    return d;
-}
 
 // generic.c:296-301 getCov, with the interval already loaded.
 __device__ __forceinline__ float itx_cov(uint32_t start, uint32_t end, int32_t s, int32_t e)
@@ -114,29 +40,24 @@ __device__ __forceinline__ int32_t clip_ov(int32_t s, int32_t e, int32_t qs, int
 struct IvGlobal {
     const ItxIv *iv;
     __device__ __forceinline__ int32_t s(uint32_t k) const { return iv[k].s; }
-    __device__ __forceinline__ void sep(uint32_t k, int32_t &s_, int32_t &e_, int32_t &pm) const
+    __device__ __forceinline__ void sep(uint32_t k, int32_t &s_, int32_t &e_, int32_t &pb) const
     {
         const uint4 v = *reinterpret_cast<const uint4 *>(&iv[k]);
-        s_ = (int32_t)v.x; e_ = (int32_t)v.y; pm = (int32_t)v.z;
+        s_ = (int32_t)v.x; e_ = (int32_t)v.y; pb = (int32_t)v.z;
     }
     __device__ __forceinline__ uint32_t rk(uint32_t k) const { return iv[k].rank; }
 };
 struct IvLds {
     const uint4 *w;            // entry j at w[2j], w[2j+1]
     __device__ __forceinline__ int32_t s(uint32_t j) const { return (int32_t)w[2 * j].x; }
-    __device__ __forceinline__ void sep(uint32_t j, int32_t &s_, int32_t &e_, int32_t &pm) const
+    __device__ __forceinline__ void sep(uint32_t j, int32_t &s_, int32_t &e_, int32_t &pb) const
     {
         const uint4 v = w[2 * j];
-        s_ = (int32_t)v.x; e_ = (int32_t)v.y; pm = (int32_t)v.z;
+        s_ = (int32_t)v.x; e_ = (int32_t)v.y; pb = (int32_t)v.z;
     }
     __device__ __forceinline__ uint32_t rk(uint32_t j) const { return w[2 * j].w; }
 };
 
-// Picks, among candidates [lo, hi) (hi = first candidate with s >= qe), the row the reference would
-// pick, or -1. Hits are rows with positive clipped overlap (binRange.c:216); the scan walks down while
-// the prefix-max of the ends still exceeds qs. One hit is the answer; with several, the reference's
-// rule "last hit, in list order, whose coverage exceeds the previous hit's" (generic.c:955-959) is
-// replayed through the precomputed list-order ranks.
 // Several hits among candidates [low, hi): replay generic.c:950-970 — walk the hits in the order
 // binKeeperFind returns them (list-order rank) and keep the LAST one whose coverage exceeds its predecessor's.
 // Returns the chosen candidate or -1 (also when its coverage is below min_cov, generic.c:961-962).
@@ -190,9 +111,8 @@ __device__ __forceinline__ int32_t itx_pick(const ACC &A, uint32_t lo, uint32_t 
     int32_t os = 0, oe = 0;
     for (uint32_t k = top; k > lo;) {
         --k;
-        int32_t s, e, pm;
-        A.sep(k, s, e, pm);
-        if (pm <= qs) break;
+        int32_t s, e, pb;
+        A.sep(k, s, e, pb);
         low = k;
         if (clip_ov(s, e, qs, qe) > 0) {
             n++;
@@ -200,6 +120,7 @@ __device__ __forceinline__ int32_t itx_pick(const ACC &A, uint32_t lo, uint32_t 
             os = s;
             oe = e;
         }
+        if (pb <= qs) break;                                       // nothing below ends past the query start
     }
     if (n == 0) return -1;
     if (n == 1) return itx_cov(ustart, uend, os, oe) < min_cov ? -1 : (int32_t)only;   // generic.c:961-962

@@ -255,6 +255,7 @@ static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_h
     ItxRunParams P;
     P.mapq_min = e->p.mapq_min;
     P.min_cov = e->p.min_cov;
+    itx_cov_bounds(P.min_cov, &P.cov_hi, &P.cov_lo);
     P.extension = e->p.extension;
     P.isize_max = e->p.isize_max;
     P.treat = e->p.treat_pe_as_se;

@@ -11,7 +11,7 @@
 //     bin j); the candidate window [lo_w, hi_w) of table rows comes out of it with two lane reads,
 //   * ONE coalesced load stages the window's rows (32 B each, <= 128 rows) into the wave's LDS window,
 //   * every record takes the top of its bin from the index slice (one ds_bpermute) and walks down the LDS
-//     window while the prefix-max of the row ends still exceeds its start; the four records of a lane advance
+//     window while the rows below still end past its start (ItxIv.pbelow); the four records of a lane advance
 //     in lockstep, one ds_read_b128 each per step.
 // Tiles that do not fit this picture (mixed chromosomes, > 64 bins or > 128 rows: unsorted or very sparse
 // input) take the per-lane global-memory lookup — slower, same results.
@@ -24,54 +24,30 @@
 #define RPL 4
 #define WTILE (64 * RPL)
 
-// generic.c:748-922 for one record, predicated. tr = first 16 bytes of the record's ItxTidRec.
-struct Derived {
-    uint32_t cntbits;      // bit k: cnt[k] += 1 for k in 0..7 (generic.c:1048-1055); cnt[11] == cnt[7] without -R
-    uint32_t start, end;
-    bool ok, uniq;
-};
-__device__ __forceinline__ Derived derive_pred(const ItxRunParams &P, const ItxRaw &r, const uint4 &tr, int32_t isz, int32_t mpos)
+// Everything generic.c:748-922 decides from a record's flag bits alone, tabulated once per workgroup.
+// Index: flag5 (5 bits) | 32 the reference is known and usable (generic.c:781-801) | 64 a proper-pair insert size
+// (generic.c:838-840) | 128 MAPQ >= -Q. Entry: bit 3k set => cnt[k] += 1 for k in 0..7 (generic.c:1048-1055;
+// cnt[11] == cnt[7] without -R), LUT_OK the record goes on to the lookup, LUT_SE it is measured as a single end.
+#define LUT_OK (1u << 24)
+#define LUT_SE (1u << 25)
+__device__ __forceinline__ uint32_t lut_entry(const ItxRunParams &P, uint32_t idx)
 {
-    Derived d;
-    const uint32_t fl = r.fl;
-    const bool paired = fl & F5_PAIRED, unmap = fl & F5_UNMAP, munmap = fl & F5_MUNMAP, rev = fl & F5_REVERSE, read1 = fl & F5_READ1;
+    const bool paired = idx & F5_PAIRED, unmap = idx & F5_UNMAP, munmap = idx & F5_MUNMAP, read1 = idx & F5_READ1;
+    const bool ref_ok = idx & 32u, isz_ok = idx & 64u, uniq = idx & 128u;
     const bool treat = P.treat != 0;
     const bool end1 = !paired || read1 || treat;                                   // generic.c:748-759
     const bool mapped = !unmap;                                                    // generic.c:764
-    const uint32_t cend = tr.y - 1u;                                               // generic.c:796
-    const bool chrom_ok = mapped && (int32_t)tr.x >= 0 && cend != 1u;              // generic.c:781-801
+    const bool chrom_ok = mapped && ref_ok;                                        // generic.c:781-801
     const bool se = treat || !paired || munmap;                                    // generic.c:815,836-837,885
-    const uint32_t aisz = isz < 0 ? 0u - (uint32_t)isz : (uint32_t)isz;
-    const bool pe_ok = read1 && aisz <= P.isize_max && isz != 0;                   // generic.c:838-840,858-860
+    const bool pe_ok = read1 && isz_ok;                                            // generic.c:838-840,858-860
     const bool se_ok = treat || !paired || P.discard == 0;                         // generic.c:862-863
-    d.ok = chrom_ok && (se ? se_ok : pe_ok);
-    d.uniq = r.mapq >= P.mapq_min;
-    // generic.c:819-833
-    uint32_t s_se = (uint32_t)r.pos;
-    uint32_t e_se = umin32(cend, (uint32_t)r.tmpend);
-    if (P.extension) {                                                             // wave-uniform
-        const uint32_t e_plus = umin32(s_se + P.extension, cend);
-        const uint32_t s_minus = e_se < P.extension ? 0u : e_se - P.extension;
-        s_se = rev ? s_minus : s_se;
-        e_se = rev ? e_se : e_plus;
-    }
-    // generic.c:845-855
-    const bool fwd = isz > 0;
-    const uint32_t s_pe = fwd ? (uint32_t)r.pos : (uint32_t)mpos;
-    const uint32_t e_pe = umin32(cend, fwd ? s_pe + (uint32_t)isz : s_pe - (uint32_t)isz);
-    d.start = se ? s_se : s_pe;
-    d.end = se ? e_se : e_pe;
-    d.cntbits = (end1 ? 1u : 2u) | (mapped ? (end1 ? 4u : 8u) : 0u) | (chrom_ok ? (end1 ? 16u : 32u) : 0u) | (d.ok ? 64u : 0u) |
-                (d.ok && d.uniq ? 128u : 0u);
-    return d;
-}
-
-// bit k of an 8-bit value -> 1 in nibble k
-__device__ __forceinline__ uint32_t spread8(uint32_t x)
-{
-    uint32_t t = (x | (x << 12)) & 0x000f000fu;
-    t = (t | (t << 3) | (t << 6) | (t << 9)) & 0x11111111u;
-    return t;
+    const bool ok = chrom_ok && (se ? se_ok : pe_ok);
+    uint32_t e = end1 ? 1u : 1u << 3;
+    e |= mapped ? (end1 ? 1u << 6 : 1u << 9) : 0u;
+    e |= chrom_ok ? (end1 ? 1u << 12 : 1u << 15) : 0u;
+    e |= ok ? 1u << 18 : 0u;
+    e |= (ok && uniq) ? 1u << 21 : 0u;
+    return e | (ok ? LUT_OK : 0u) | (se ? LUT_SE : 0u);
 }
 
 __device__ __forceinline__ uint32_t uadd32(uint32_t a, uint32_t b) { return a + b; }
@@ -86,26 +62,45 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// The two-hit rule of generic.c:950-970 on integers: of two hits, the one that comes first in binKeeperFind's
+// list order (smaller rank) is kept unless the other's overlap is larger. h = the hit found last by the scan,
+// g = the one before it; returns the chosen window index and its overlap. With a single hit g is unused.
+__device__ __forceinline__ void pick_of_two(bool two, uint32_t h_k, uint32_t h_ov, uint32_t h_rk, uint32_t g_k, uint32_t g_ov, uint32_t g_rk,
+                                            uint32_t *ck, uint32_t *cov)
+{
+    const bool h_first = h_rk < g_rk;
+    const uint32_t ov1 = h_first ? h_ov : g_ov, ov2 = h_first ? g_ov : h_ov;
+    const uint32_t k1 = h_first ? h_k : g_k, k2 = h_first ? g_k : h_k;
+    const bool second = two && ov2 > ov1;
+    *ck = two ? (second ? k2 : k1) : h_k;
+    *cov = two ? (second ? ov2 : ov1) : h_ov;
+}
+
 template <int WHAT>
 __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
                                                int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64,
                                                uint32_t *__restrict__ u32, ItxAccumLayout L, uint32_t *__restrict__ keys0,
                                                uint32_t *__restrict__ blk_cnt, ItxEmitPlan E)
 {
-    __shared__ uint4 s_win[SB / 64][2 * ITX_WIN];
+    // a wave's window: entry 0 is a sentinel no query overlaps and no scan walks past, table row lo_w + i sits at entry i + 1
+    __shared__ uint4 s_win[SB / 64][2 * (ITX_WIN + 1)];
     __shared__ uint32_t s_lut[256];
     __shared__ uint32_t s_cnt[16];
     __shared__ uint32_t s_cursor;
     extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
-    s_lut[threadIdx.x] = spread8(threadIdx.x);
-    if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_cursor = 0;
-    if (WHAT == ITX_DO_EMIT)
-        for (uint32_t k = threadIdx.x; k < E.n_part; k += SB) s_pc[k] = 0;
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     uint4 *win = s_win[w];
+    s_lut[threadIdx.x] = lut_entry(P, threadIdx.x);
+    if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_cursor = 0;
+    if (lane == 0) {
+        win[0] = make_uint4(0x3fffffffu, 0xc0000000u, 0x80000000u, 0xffffffffu);      // s, e, pbelow, rank
+        win[1] = make_uint4(0, 0, 0, 0);
+    }
+    if (WHAT == ITX_DO_EMIT)
+        for (uint32_t k = threadIdx.x; k < E.n_part; k += SB) s_pc[k] = 0;
+    __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
     const size_t begin = (size_t)blockIdx.x * span;
     size_t end = begin + span;
@@ -117,8 +112,10 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
     int32_t cur_tid = -0x7fffffff;
     uint4 cur0 = make_uint4(0xffffffffu, 0, 0, 0);
     uint32_t cur_bb = 0;
-    // per-lane counters (generic.c:1048-1060), reduced over the wave once at the end
-    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc_hit = 0, acc_hitu = 0;
+    // cnt[0..7] (generic.c:1048-1055): per-lane sums in 6-bit fields (even counters in accA, odd ones in accB), spilled
+    // into full words before a field can overflow; hits (generic.c:1030-1032) are counted per wave from ballots
+    uint32_t accA = 0, accB = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t n_hit = 0, n_hitu = 0, tiles = 0;
 #ifdef ITX_ABLATE
     uint32_t sink = 0;      // timing-only builds: stop the tile early, keep what was computed alive
 #define ITX_ABLATE_AT(k, expr) if (ITX_ABLATE == (k)) { sink += (expr); continue; }
@@ -132,19 +129,21 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
         ItxRaw raw[RPL];
         bool ex[RPL];
         int32_t isz[RPL] = {0, 0, 0, 0}, mps[RPL] = {0, 0, 0, 0};
+        bool tile_pe = have_pe;                                                 // wave-uniform: mate fields were read
         if (full) {
             const int4 t4 = *reinterpret_cast<const int4 *>(B.tid + r0);
             const int4 p4 = *reinterpret_cast<const int4 *>(B.pos + r0);
             const int4 e4 = *reinterpret_cast<const int4 *>(B.tmpend + r0);
             const uint32_t mq = *reinterpret_cast<const uint32_t *>(B.mapq + r0);
             const uint32_t f4 = *reinterpret_cast<const uint32_t *>(B.flag5 + r0);
-            raw[0] = {t4.x, p4.x, e4.x, mq & 0xffu, f4 & 0xffu};
-            raw[1] = {t4.y, p4.y, e4.y, (mq >> 8) & 0xffu, (f4 >> 8) & 0xffu};
-            raw[2] = {t4.z, p4.z, e4.z, (mq >> 16) & 0xffu, (f4 >> 16) & 0xffu};
-            raw[3] = {t4.w, p4.w, e4.w, mq >> 24, f4 >> 24};
+            raw[0] = {t4.x, p4.x, e4.x, mq & 0xffu, f4 & 0x1fu};
+            raw[1] = {t4.y, p4.y, e4.y, (mq >> 8) & 0xffu, (f4 >> 8) & 0x1fu};
+            raw[2] = {t4.z, p4.z, e4.z, (mq >> 16) & 0xffu, (f4 >> 16) & 0x1fu};
+            raw[3] = {t4.w, p4.w, e4.w, mq >> 24, (f4 >> 24) & 0x1fu};
 #pragma unroll
             for (int j = 0; j < RPL; j++) ex[j] = true;
-            if (have_pe && __ballot(f4 & 0x01010101u)) {                        // some record of the tile is paired
+            tile_pe = have_pe && __ballot(f4 & 0x01010101u) != 0ull;            // some record of the tile is paired
+            if (tile_pe) {
                 const int4 i4 = *reinterpret_cast<const int4 *>(B.isize + r0);
                 const int4 m4 = *reinterpret_cast<const int4 *>(B.mpos + r0);
                 isz[0] = i4.x; isz[1] = i4.y; isz[2] = i4.z; isz[3] = i4.w;
@@ -156,7 +155,7 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
                 ex[j] = r0 + j < end;
                 raw[j] = {0, 0, 0, 0, 0};
                 if (ex[j]) {
-                    raw[j] = {B.tid[r0 + j], B.pos[r0 + j], B.tmpend[r0 + j], B.mapq[r0 + j], B.flag5[r0 + j]};
+                    raw[j] = {B.tid[r0 + j], B.pos[r0 + j], B.tmpend[r0 + j], B.mapq[r0 + j], B.flag5[r0 + j] & 0x1fu};
                     if (have_pe) {
                         isz[j] = B.isize[r0 + j];
                         mps[j] = B.mpos[r0 + j];
@@ -185,12 +184,12 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
         }
         const bool uniform = __ballot(!same) == 0ull;
 
-        // ---- derive
-        Derived d[RPL];
+        // ---- derive (generic.c:748-922): flag logic from the table, coordinates predicated
         uint4 tr[RPL];
         uint32_t bb[RPL];
+        uint32_t lut[RPL], st[RPL], en[RPL];       // st/en: the reference's unsigned start/end
         int32_t qs[RPL], qe[RPL];
-        bool q[RPL];
+        bool q[RPL], uq[RPL];
         bool anyq = false;
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
@@ -211,18 +210,43 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
         }
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            d[j] = derive_pred(P, raw[j], tr[j], isz[j], mps[j]);
-            if (!ex[j]) {
-                d[j].cntbits = 0;
-                d[j].ok = false;
+            const uint32_t cend = tr[j].y - 1u;                                            // generic.c:796
+            uq[j] = raw[j].mapq >= P.mapq_min;
+            uint32_t idx = raw[j].fl | (((int32_t)tr[j].x >= 0 && cend != 1u) ? 32u : 0u) | (uq[j] ? 128u : 0u);
+            // generic.c:819-833
+            uint32_t s_se = (uint32_t)raw[j].pos;
+            uint32_t e_se = umin32(cend, (uint32_t)raw[j].tmpend);
+            if (P.extension) {                                                             // wave-uniform
+                const bool rev = raw[j].fl & F5_REVERSE;
+                const uint32_t e_plus = umin32(s_se + P.extension, cend);
+                const uint32_t s_minus = e_se < P.extension ? 0u : e_se - P.extension;
+                s_se = rev ? s_minus : s_se;
+                e_se = rev ? e_se : e_plus;
+            }
+            st[j] = s_se;
+            en[j] = e_se;
+            bool se = true;
+            if (tile_pe) {                                                                 // wave-uniform; generic.c:838-855
+                const int32_t iz = isz[j];
+                const uint32_t aisz = iz < 0 ? 0u - (uint32_t)iz : (uint32_t)iz;
+                idx |= (aisz <= P.isize_max && iz != 0) ? 64u : 0u;
+                lut[j] = ex[j] ? s_lut[idx] : 0u;
+                se = lut[j] & LUT_SE;
+                const bool fwd = iz > 0;
+                const uint32_t s_pe = fwd ? (uint32_t)raw[j].pos : (uint32_t)mps[j];
+                const uint32_t e_pe = umin32(cend, fwd ? s_pe + (uint32_t)iz : s_pe - (uint32_t)iz);
+                st[j] = se ? s_se : s_pe;
+                en[j] = se ? e_se : e_pe;
+            } else {
+                lut[j] = ex[j] ? s_lut[idx] : 0u;
             }
             // binKeeperFind(bk, int start, int end) with its clipping (binRange.c:204-206)
-            qs[j] = imax32((int32_t)d[j].start, 0);
-            qe[j] = imin32((int32_t)d[j].end, (int32_t)tr[j].y);
-            q[j] = d[j].ok && qs[j] < qe[j] && tr[j].z < tr[j].w;
+            qs[j] = imax32((int32_t)st[j], 0);
+            qe[j] = imin32((int32_t)en[j], (int32_t)tr[j].y);
+            q[j] = (lut[j] & LUT_OK) && qs[j] < qe[j] && tr[j].z < tr[j].w;
             anyq = anyq || q[j];
         }
-        ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + (uint32_t)qs[2] + (uint32_t)qe[3] + d[0].cntbits + d[1].cntbits + d[2].cntbits + d[3].cntbits)
+        ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + (uint32_t)qs[2] + (uint32_t)qe[3] + lut[0] + lut[1] + lut[2] + lut[3])
 
         // ---- classify
         int32_t hit[RPL] = {-1, -1, -1, -1};
@@ -256,94 +280,101 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
             if (fast) {
                 if (wn) {
                     const uint4 *src = reinterpret_cast<const uint4 *>(T.iv + lo_w);
-                    for (uint32_t k = lane; k < 2 * wn; k += 64) win[k] = src[k];       // coalesced, 16 B per lane
+                    for (uint32_t k = lane; k < 2 * wn; k += 64) win[2 + k] = src[k];   // coalesced, 16 B per lane
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     ITX_ABLATE_AT(3, win[2 * (lane % wn)].x + wn)
                     // Candidates of a record: window rows below the top of qe's bin (one lane read of the index
                     // slice); rows starting at or after qe fail the overlap test by themselves. The four records of a
-                    // lane walk down in lockstep while the prefix-max of the ends still exceeds qs
-                    // (binRange.c:209-225 without the bin lists).
-                    uint32_t kk[RPL], top[RPL], low[RPL];
-                    uint32_t h_k[RPL], h_ov[RPL], h_rk[RPL];      // the hit found last (lowest row so far)
-                    uint32_t g_k[RPL], g_ov[RPL], g_rk[RPL];      // the hit found before it
-                    int32_t nh[RPL];
-                    bool act[RPL];
-                    bool any = false;
+                    // lane walk down in lockstep, entry kk then kk-1 ..., and the wave goes on while any record's current
+                    // row says rows below it still end past the query start (pbelow > qs; binRange.c:209-225 without the
+                    // bin lists). pbelow only shrinks on the way down and a row that ends at or before qs cannot overlap,
+                    // so records that are done just keep stepping, count nothing, and come to rest on the sentinel.
+                    uint32_t kk[RPL], top[RPL];
+                    uint32_t h_k[RPL], h_ov[RPL];                 // the hit found last (lowest row so far)
+                    uint32_t g_k[RPL], g_ov[RPL];                 // the hit found before it
+                    uint32_t nh[RPL];
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        const uint32_t b = q[j] ? ((uint32_t)qe[j] >> T.shift) - bin_lo + 1u : 0u;
+                        const uint32_t b = (((uint32_t)qe[j] >> T.shift) - bin_lo + 1u) & 63u;
                         uint32_t h1 = (uint32_t)__shfl((int32_t)bs.x, (int)b, 64);
                         h1 = h1 > lo_w ? h1 - lo_w : 0u;
-                        top[j] = kk[j] = low[j] = h1;
-                        act[j] = q[j] && h1 > 0;
+                        h1 = q[j] ? h1 : 0u;
+                        top[j] = kk[j] = h1;                      // rows [0, h1) <=> entries [1, h1]
                         nh[j] = 0;
-                        h_k[j] = h_ov[j] = h_rk[j] = g_k[j] = g_ov[j] = g_rk[j] = 0;
-                        any = any || act[j];
+                        h_k[j] = h_ov[j] = g_k[j] = g_ov[j] = 0;
                     }
-                    while (any) {
+                    bool any;
+                    do {
                         uint4 v[RPL];
 #pragma unroll
-                        for (int j = 0; j < RPL; j++) {
-                            kk[j] = act[j] ? kk[j] - 1 : 0u;
-                            v[j] = win[2 * kk[j]];                                      // s, e, pmax_e, rank
-                        }
+                        for (int j = 0; j < RPL; j++) v[j] = win[2 * kk[j]];              // s, e, pbelow, rank
                         any = false;
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
-                            const bool alive = act[j] && (int32_t)v[j].z > qs[j];
                             const int32_t ov = clip_ov((int32_t)v[j].x, (int32_t)v[j].y, qs[j], qe[j]);
-                            const bool ovl = alive && ov > 0;
-                            nh[j] += ovl ? 1 : 0;
+                            const bool ovl = ov > 0;
+                            nh[j] += ovl ? 1u : 0u;
                             g_k[j] = ovl ? h_k[j] : g_k[j];
                             g_ov[j] = ovl ? h_ov[j] : g_ov[j];
-                            g_rk[j] = ovl ? h_rk[j] : g_rk[j];
                             h_k[j] = ovl ? kk[j] : h_k[j];
                             h_ov[j] = ovl ? (uint32_t)ov : h_ov[j];
-                            h_rk[j] = ovl ? v[j].w : h_rk[j];
-                            low[j] = alive ? kk[j] : low[j];
-                            act[j] = alive && kk[j] > 0;
-                            any = any || act[j];
+                            any = any || (int32_t)v[j].z > qs[j];
+                            kk[j] = kk[j] ? kk[j] - 1u : 0u;
                         }
-                    }
+                    } while (__ballot(any));
                     // Best hit (generic.c:950-970): in binKeeperFind's list order, the LAST hit whose coverage exceeds the
                     // previous hit's. All hits of a record share the denominator (end - start) and, for overlaps below
                     // 2^23, distinct integer overlaps give distinct f32 quotients — so with two hits the pick is an integer
-                    // comparison on (rank, overlap); three or more hits (or giant fragments) replay the rule in full.
-                    bool multi = false;
+                    // comparison on (rank, overlap), and the -c test one multiply (itx_cov_bounds). Three or more hits,
+                    // giant fragments and quotients within 2^-20 of -c replay the reference's arithmetic in full.
+                    bool rare[RPL], anyrare = false;
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        const bool h_first = h_rk[j] < g_rk[j];                        // which of the two comes first in list order
-                        const uint32_t ov1 = h_first ? h_ov[j] : g_ov[j], ov2 = h_first ? g_ov[j] : h_ov[j];
-                        const uint32_t k1 = h_first ? h_k[j] : g_k[j], k2 = h_first ? g_k[j] : h_k[j];
-                        const bool two = nh[j] == 2;
-                        const bool second = two && ov2 > ov1;
-                        const uint32_t ck = two ? (second ? k2 : k1) : h_k[j];
-                        const uint32_t cov_ov = two ? (second ? ov2 : ov1) : h_ov[j];
-                        const uint32_t qlen = d[j].end - d[j].start;
-                        const float c = __fdiv_rn((float)cov_ov, (float)qlen);          // generic.c:296-301 (qlen > 0 for any hit)
-                        const bool big = qlen >= (1u << 23);
-                        const bool simple = (nh[j] == 1 || two) && !big;
-                        hit[j] = (simple && !(c < P.min_cov)) ? (int32_t)ck : -1;       // generic.c:961-962
-                        multi = multi || (nh[j] > 0 && !simple);
+                        const uint32_t h_rk = win[2 * h_k[j]].w, g_rk = win[2 * g_k[j]].w;
+                        uint32_t ck, cov_ov;
+                        pick_of_two(nh[j] == 2, h_k[j], h_ov[j], h_rk, g_k[j], g_ov[j], g_rk, &ck, &cov_ov);
+                        const uint32_t qlen = en[j] - st[j];
+                        const bool simple = (nh[j] == 1 || nh[j] == 2) && qlen < (1u << 23);
+                        const float ovf = (float)cov_ov, qf = (float)qlen;
+                        const bool pass = ovf >= qf * P.cov_hi, fail = ovf < qf * P.cov_lo;
+                        hit[j] = (simple && pass) ? (int32_t)ck : -1;
+                        rare[j] = nh[j] > 0 && !(simple && (pass || fail));
+                        anyrare = anyrare || rare[j];
                     }
-                    if (__ballot(multi)) {                                              // three or more hits / giant fragments: rare
-                        IvLds A{win};
+                    if (__ballot(anyrare)) {
+                        IvLds A{win + 2};
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
-                            const bool simple = (nh[j] == 1 || nh[j] == 2) && (d[j].end - d[j].start) < (1u << 23);
-                            if (nh[j] > 0 && !simple)
-                                hit[j] = itx_pick_multi(A, low[j], top[j], qs[j], qe[j], d[j].start, d[j].end, P.min_cov);
+                            if (rare[j]) {
+                                const uint32_t qlen = en[j] - st[j];
+                                if ((nh[j] == 1 || nh[j] == 2) && qlen < (1u << 23)) {
+                                    const uint32_t h_rk = win[2 * h_k[j]].w, g_rk = win[2 * g_k[j]].w;
+                                    uint32_t ck, cov_ov;
+                                    pick_of_two(nh[j] == 2, h_k[j], h_ov[j], h_rk, g_k[j], g_ov[j], g_rk, &ck, &cov_ov);
+                                    const float c = __fdiv_rn((float)cov_ov, (float)qlen);     // generic.c:296-301
+                                    hit[j] = !(c < P.min_cov) ? (int32_t)ck : -1;              // generic.c:961-962
+                                } else {
+                                    uint32_t low = top[j];                                     // rows [low, top) can overlap
+                                    while (low > 0) {
+                                        const int32_t pb = (int32_t)win[2 * low].z;
+                                        low--;
+                                        if (pb <= qs[j]) break;
+                                    }
+                                    const int32_t r = itx_pick_multi(A, low, top[j], qs[j], qe[j], st[j], en[j], P.min_cov);
+                                    hit[j] = r >= 0 ? r + 1 : -1;
+                                }
+                            }
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
                         const uint32_t k = hit[j] >= 0 ? (uint32_t)hit[j] : 0u;
                         const uint4 v0 = win[2 * k], v1 = win[2 * k + 1];
-                        rec[j].s = (int32_t)v0.x; rec[j].e = (int32_t)v0.y; rec[j].pmax_e = (int32_t)v0.z; rec[j].rank = v0.w;
+                        rec[j].s = (int32_t)v0.x; rec[j].e = (int32_t)v0.y; rec[j].pbelow = (int32_t)v0.z; rec[j].rank = v0.w;
                         rec[j].cs = v1.x; rec[j].jcap = v1.y; rec[j].covslot = v1.z; rec[j].zslot = v1.w;
-                        hit[j] = hit[j] >= 0 ? hit[j] + (int32_t)lo_w : -1;
+                        hit[j] = hit[j] >= 0 ? hit[j] - 1 + (int32_t)lo_w : -1;
                     }
                     __builtin_amdgcn_wave_barrier();                                    // the window is rewritten next tile
                 }
@@ -351,7 +382,7 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
 #pragma unroll
                 for (int j = 0; j < RPL; j++) {
                     if (q[j]) {
-                        hit[j] = itx_classify_lane(T, tr[j].z, bb[j], qs[j], qe[j], d[j].start, d[j].end, P.min_cov);
+                        hit[j] = itx_classify_lane(T, tr[j].z, bb[j], qs[j], qe[j], st[j], en[j], P.min_cov);
                         if (hit[j] >= 0) rec[j] = T.iv[hit[j]];
                     }
                 }
@@ -359,18 +390,28 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
         }
         ITX_ABLATE_AT(4, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]))
 
-        // ---- cnt[] (generic.c:1048-1060): nibble-wise per-lane sums of the four records' bits
+        // ---- cnt[] (generic.c:1048-1060)
+        unsigned long long mA[RPL];
         {
-            const uint32_t n4 = s_lut[d[0].cntbits] + s_lut[d[1].cntbits] + s_lut[d[2].cntbits] + s_lut[d[3].cntbits];
+            const uint32_t n4 = lut[0] + lut[1] + lut[2] + lut[3];                      // 3-bit fields, each <= 4
+            accA += n4 & 0x1c71c7u;
+            accB += (n4 >> 3) & 0x1c71c7u;
+            if (++tiles == 15) {                                                        // 15 * 4 < 64
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc[k] += (n4 >> (4 * k)) & 0xfu;
+                for (int k = 0; k < 4; k++) {
+                    acc[2 * k] += (accA >> (6 * k)) & 63u;
+                    acc[2 * k + 1] += (accB >> (6 * k)) & 63u;
+                }
+                accA = accB = tiles = 0;
+            }
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
-                acc_hit += hit[j] >= 0 ? 1u : 0u;                                       // generic.c:1030-1032
-                acc_hitu += (hit[j] >= 0 && d[j].uniq) ? 1u : 0u;
+                mA[j] = __ballot(hit[j] >= 0);                                          // generic.c:1030-1032
+                n_hit += (uint32_t)__popcll(mA[j]);
+                n_hitu += (uint32_t)__popcll(mA[j] & __ballot(uq[j]));
             }
         }
-        ITX_ABLATE_AT(5, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]) + acc[0] + acc_hit)
+        ITX_ABLATE_AT(5, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]) + accA + n_hit)
 
         // ---- chosen rows back to the caller (row ids as passed to itx_table_create)
         if (d_hit_row) {
@@ -392,17 +433,17 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
             for (int j = 0; j < RPL; j++) {
                 if (hit[j] >= 0) {
                     uint32_t first;
-                    const uint32_t nc = itx_cov_range(rec[j], d[j].start, d[j].end, &first);
+                    const uint32_t nc = itx_cov_range(rec[j], st[j], en[j], &first);
                     if (nc) {
                         atomicAdd(&u32[L.a_all + first], 1u);
                         atomicAdd(&u32[L.b_all + first + nc], 1u);
-                        if (d[j].uniq) {
+                        if (uq[j]) {
                             atomicAdd(&u32[L.a_uniq + first], 1u);
                             atomicAdd(&u32[L.b_uniq + first + nc], 1u);
                         }
                     } else {
                         atomicAdd(&u32[L.a_all + rec[j].zslot], 1u);
-                        if (d[j].uniq) atomicAdd(&u32[L.a_uniq + rec[j].zslot], 1u);
+                        if (uq[j]) atomicAdd(&u32[L.a_uniq + rec[j].zslot], 1u);
                     }
                 }
             }
@@ -417,17 +458,16 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
             uint32_t kA[RPL], kB[RPL];
             bool hA[RPL], hB[RPL];
             uint32_t total = 0;
-            unsigned long long mA[RPL], mB[RPL];
+            unsigned long long mB[RPL];
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 uint32_t first;
-                const uint32_t nc = itx_cov_range(rec[j], d[j].start, d[j].end, &first);
-                const uint32_t u = d[j].uniq ? 1u : 0u;
+                const uint32_t nc = itx_cov_range(rec[j], st[j], en[j], &first);
+                const uint32_t u = uq[j] ? 1u : 0u;
                 hA[j] = hit[j] >= 0;
                 hB[j] = hA[j] && nc != 0;
                 kA[j] = ((hB[j] ? first : rec[j].zslot) << 2) | u;                     // no coverage: one start in the unit's extra slot
                 kB[j] = ((first + nc) << 2) | 2u | u;
-                mA[j] = __ballot(hA[j]);
                 mB[j] = __ballot(hB[j]);
                 total += (uint32_t)__popcll(mA[j]) + (uint32_t)__popcll(mB[j]);
             }
@@ -451,18 +491,21 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
     if (sink == 0x7fffff01u) s_cnt[12] = sink;
 #endif
     if (WHAT != ITX_DO_CLASSIFY) {                        // classify-only launches leave every accumulator alone
-        uint32_t tot[10];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            acc[2 * k] += (accA >> (6 * k)) & 63u;
+            acc[2 * k + 1] += (accB >> (6 * k)) & 63u;
+        }
+        uint32_t tot[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) tot[k] = wave_sum_u32(acc[k]);
-        tot[8] = wave_sum_u32(acc_hit);
-        tot[9] = wave_sum_u32(acc_hitu);
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 if (tot[k]) atomicAdd(&s_cnt[k], tot[k]);
             if (tot[7]) atomicAdd(&s_cnt[11], tot[7]);    // reads_nonredundant_unique == reads_mapped_unique without -R
-            if (tot[8]) atomicAdd(&s_cnt[9], tot[8]);
-            if (tot[9]) atomicAdd(&s_cnt[10], tot[9]);
+            if (n_hit) atomicAdd(&s_cnt[9], n_hit);
+            if (n_hitu) atomicAdd(&s_cnt[10], n_hitu);
         }
     }
     __syncthreads();

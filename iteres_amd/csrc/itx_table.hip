@@ -7,7 +7,7 @@
 // beats the previous hit's"). Here the rows of a chromosome are one start-sorted array with
 //   * a binned index `bl` (per 2^shift bp: first row starting in/after the bin, first row whose
 //     prefix-max end passes the bin start) bounding the candidate range from both sides in O(1),
-//   * a prefix-maximum of the ends (pmax_e) as the scan-stop bound, and
+//   * a prefix-maximum of the ends of the rows below (pbelow) as the scan-stop bound, and
 //   * each row's RANK in binKeeperFind's return order (level coarse->fine, bin descending,
 //     insertion ascending — cuskent/binRange.c:209-225) so the kernel can replay the best-hit rule
 //     exactly without the bin lists.
@@ -199,8 +199,8 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
             ItxIv &d = iv[k];
             d.s = (int32_t)r.start;
             d.e = (int32_t)r.end;
+            d.pbelow = pm;
             pm = std::max(pm, d.e);
-            d.pmax_e = pm;
             d.cs = r.cons_start;
             const uint32_t len = rep_len[r.rep];
             const uint32_t u = unit_of_row[order[k]];
@@ -212,10 +212,11 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         }
         uint32_t nb = bin_off[c + 1] - bin_off[c];
         uint32_t k = lo, m = lo;
+        auto pmax = [&](uint32_t r) { return std::max(iv[r].pbelow, iv[r].e); };
         for (uint32_t b = 0; b < nb; b++) {
             int64_t bound = (int64_t)b << shift;
             while (k < hi && (int64_t)iv[k].s < bound) k++;          // first row starting at or after the bin
-            while (m < hi && (int64_t)iv[m].pmax_e <= bound) m++;    // first row whose prefix-max end passes the bin start
+            while (m < hi && (int64_t)pmax(m) <= bound) m++;         // first row whose prefix-max end passes the bin start
             bl[bin_off[c] + b] = make_uint2(k, m);
         }
     }

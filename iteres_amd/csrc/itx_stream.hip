@@ -21,6 +21,9 @@
 #include "itx_device.h"
 
 #define SB 256
+#ifndef ITX_LB
+#define ITX_LB 4          // workgroups per CU the register budget is set for
+#endif
 #define RPL 4
 #define WTILE (64 * RPL)
 
@@ -62,29 +65,79 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// The two-hit rule of generic.c:950-970 on integers: of two hits, the one that comes first in binKeeperFind's
-// list order (smaller rank) is kept unless the other's overlap is larger. h = the hit found last by the scan,
-// g = the one before it; returns the chosen window index and its overlap. With a single hit g is unused.
-__device__ __forceinline__ void pick_of_two(bool two, uint32_t h_k, uint32_t h_ov, uint32_t h_rk, uint32_t g_k, uint32_t g_ov, uint32_t g_rk,
-                                            uint32_t *ck, uint32_t *cov)
+// Top of a record's candidates as a window entry: the first row starting at or after the end of qe's bin, from
+// the wave's slice of the binned index (lane i holds bin bin_lo + i), relative to the window start.
+__device__ __forceinline__ uint32_t top_entry(uint32_t bsx, int32_t qe, int32_t shift, uint32_t bin_lo, uint32_t lo_w)
 {
-    const bool h_first = h_rk < g_rk;
-    const uint32_t ov1 = h_first ? h_ov : g_ov, ov2 = h_first ? g_ov : h_ov;
-    const uint32_t k1 = h_first ? h_k : g_k, k2 = h_first ? g_k : h_k;
-    const bool second = two && ov2 > ov1;
-    *ck = two ? (second ? k2 : k1) : h_k;
-    *cov = two ? (second ? ov2 : ov1) : h_ov;
+    const uint32_t b = (((uint32_t)qe >> shift) - bin_lo + 1u) & 63u;
+    const uint32_t h1 = (uint32_t)__shfl((int32_t)bsx, (int)b, 64);
+    return __builtin_elementwise_sub_sat(h1, lo_w);
+}
+
+// generic.c:748-922 for one record. (tx, ty) = chrom and size of the record's ItxTidRec, has_rows = its reference
+// has table rows. Out: the flag table's entry, the reference's unsigned start/end, binKeeperFind's clipped query
+// (binRange.c:204-206), whether the record goes on to the lookup, and MAPQ >= -Q.
+__device__ __forceinline__ void derive_one(const ItxRunParams &P, const uint32_t *s_lut, const ItxRaw &r, int32_t iz, int32_t mpos, bool tile_pe,
+                                           uint32_t tx, uint32_t ty, bool has_rows, uint32_t &lut, uint32_t &st, uint32_t &en, int32_t &qs,
+                                           int32_t &qe, bool &q, bool &uq)
+{
+    const uint32_t cend = ty - 1u;                                                 // generic.c:796
+    uq = r.mapq >= P.mapq_min;
+    uint32_t idx = r.fl | (((int32_t)tx >= 0 && cend != 1u) ? 32u : 0u) | (uq ? 128u : 0u);
+    // generic.c:819-833
+    uint32_t s_se = (uint32_t)r.pos;
+    uint32_t e_se = umin32(cend, (uint32_t)r.tmpend);
+    if (P.extension) {                                                             // wave-uniform
+        const bool rev = r.fl & F5_REVERSE;
+        const uint32_t e_plus = umin32(s_se + P.extension, cend);
+        const uint32_t s_minus = __builtin_elementwise_sub_sat(e_se, P.extension);
+        s_se = rev ? s_minus : s_se;
+        e_se = rev ? e_se : e_plus;
+    }
+    st = s_se;
+    en = e_se;
+    if (tile_pe) {                                                                 // wave-uniform; generic.c:838-855
+        const uint32_t aisz = iz < 0 ? 0u - (uint32_t)iz : (uint32_t)iz;
+        idx |= (aisz <= P.isize_max && iz != 0) ? 64u : 0u;
+        lut = s_lut[idx];
+        const bool se = lut & LUT_SE;
+        const bool fwd = iz > 0;
+        const uint32_t s_pe = fwd ? (uint32_t)r.pos : (uint32_t)mpos;
+        const uint32_t e_pe = umin32(cend, fwd ? s_pe + (uint32_t)iz : s_pe - (uint32_t)iz);
+        st = se ? s_se : s_pe;
+        en = se ? e_se : e_pe;
+    } else {
+        lut = s_lut[idx];
+    }
+    qs = imax32((int32_t)st, 0);
+    qe = imin32((int32_t)en, (int32_t)ty);
+    q = (lut & LUT_OK) && qs < qe && has_rows;
+}
+
+// One record classified straight from global memory (any record order), and the slots its chosen row marks.
+__device__ __forceinline__ void classify_global(const ItxDevTable &T, const ItxRunParams &P, uint32_t iv_lo, uint32_t bin_base, int32_t qs, int32_t qe,
+                                                uint32_t st, uint32_t en, int32_t &hit, uint32_t &sA, uint32_t &sB, bool &hB)
+{
+    hit = itx_classify_lane(T, iv_lo, bin_base, qs, qe, st, en, P.min_cov);
+    if (hit >= 0) {
+        const ItxIv r = T.iv[hit];
+        uint32_t first;
+        const uint32_t nc = itx_cov_range(r, st, en, &first);
+        hB = nc != 0;
+        sA = hB ? first : r.zslot;
+        sB = first + nc;
+    }
 }
 
 template <int WHAT>
-__global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
+__global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
                                                int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64,
                                                uint32_t *__restrict__ u32, ItxAccumLayout L, uint32_t *__restrict__ keys0,
                                                uint32_t *__restrict__ blk_cnt, ItxEmitPlan E)
 {
     // a wave's window: entry 0 is a sentinel no query overlaps and no scan walks past, table row lo_w + i sits at entry i + 1
     __shared__ uint4 s_win[SB / 64][2 * (ITX_WIN + 1)];
-    __shared__ uint32_t s_lut[256];
+    __shared__ uint32_t s_lut[512];                            // entries 256.. are zero: records past the end carry fl = 256
     __shared__ uint32_t s_cnt[16];
     __shared__ uint32_t s_cursor;
     extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
@@ -92,6 +145,7 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
     const uint32_t w = threadIdx.x >> 6;
     uint4 *win = s_win[w];
     s_lut[threadIdx.x] = lut_entry(P, threadIdx.x);
+    s_lut[256 + threadIdx.x] = 0;
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_cursor = 0;
     if (lane == 0) {
@@ -113,8 +167,8 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
     uint4 cur0 = make_uint4(0xffffffffu, 0, 0, 0);
     uint32_t cur_bb = 0;
     // cnt[0..7] (generic.c:1048-1055): per-lane sums in 6-bit fields (even counters in accA, odd ones in accB), spilled
-    // into full words before a field can overflow; hits (generic.c:1030-1032) are counted per wave from ballots
-    uint32_t accA = 0, accB = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // into 16-bit halves before a field can overflow (itx_launch_stream bounds the tiles per wave); hits (generic.c:1030-1032) are counted per wave from ballots
+    uint32_t accA = 0, accB = 0, acc[4] = {0, 0, 0, 0};        // acc[k]: cnt[2k] | cnt[2k+1] << 16
     uint32_t n_hit = 0, n_hitu = 0, tiles = 0;
 #ifdef ITX_ABLATE
     uint32_t sink = 0;      // timing-only builds: stop the tile early, keep what was computed alive
@@ -153,7 +207,7 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 ex[j] = r0 + j < end;
-                raw[j] = {0, 0, 0, 0, 0};
+                raw[j] = {0, 0, 0, 0, 256u};
                 if (ex[j]) {
                     raw[j] = {B.tid[r0 + j], B.pos[r0 + j], B.tmpend[r0 + j], B.mapq[r0 + j], B.flag5[r0 + j] & 0x1fu};
                     if (have_pe) {
@@ -185,12 +239,15 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
         const bool uniform = __ballot(!same) == 0ull;
 
         // ---- derive (generic.c:748-922): flag logic from the table, coordinates predicated
-        uint4 tr[RPL];
-        uint32_t bb[RPL];
         uint32_t lut[RPL], st[RPL], en[RPL];       // st/en: the reference's unsigned start/end
         int32_t qs[RPL], qe[RPL];
         bool q[RPL], uq[RPL];
         bool anyq = false;
+        int32_t hit[RPL] = {-1, -1, -1, -1};
+        uint32_t sA[RPL] = {0, 0, 0, 0}, sB[RPL] = {0, 0, 0, 0};  // slots of the start / end marks of the chosen row's consensus range
+        bool hB[RPL] = {false, false, false, false};              // the read adds coverage (else: one start in the unit's extra slot)
+        uint4 tr[RPL];
+        uint32_t bb[RPL];
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             tr[j] = cur0;
@@ -210,49 +267,24 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
         }
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            const uint32_t cend = tr[j].y - 1u;                                            // generic.c:796
-            uq[j] = raw[j].mapq >= P.mapq_min;
-            uint32_t idx = raw[j].fl | (((int32_t)tr[j].x >= 0 && cend != 1u) ? 32u : 0u) | (uq[j] ? 128u : 0u);
-            // generic.c:819-833
-            uint32_t s_se = (uint32_t)raw[j].pos;
-            uint32_t e_se = umin32(cend, (uint32_t)raw[j].tmpend);
-            if (P.extension) {                                                             // wave-uniform
-                const bool rev = raw[j].fl & F5_REVERSE;
-                const uint32_t e_plus = umin32(s_se + P.extension, cend);
-                const uint32_t s_minus = e_se < P.extension ? 0u : e_se - P.extension;
-                s_se = rev ? s_minus : s_se;
-                e_se = rev ? e_se : e_plus;
-            }
-            st[j] = s_se;
-            en[j] = e_se;
-            bool se = true;
-            if (tile_pe) {                                                                 // wave-uniform; generic.c:838-855
-                const int32_t iz = isz[j];
-                const uint32_t aisz = iz < 0 ? 0u - (uint32_t)iz : (uint32_t)iz;
-                idx |= (aisz <= P.isize_max && iz != 0) ? 64u : 0u;
-                lut[j] = ex[j] ? s_lut[idx] : 0u;
-                se = lut[j] & LUT_SE;
-                const bool fwd = iz > 0;
-                const uint32_t s_pe = fwd ? (uint32_t)raw[j].pos : (uint32_t)mps[j];
-                const uint32_t e_pe = umin32(cend, fwd ? s_pe + (uint32_t)iz : s_pe - (uint32_t)iz);
-                st[j] = se ? s_se : s_pe;
-                en[j] = se ? e_se : e_pe;
-            } else {
-                lut[j] = ex[j] ? s_lut[idx] : 0u;
-            }
-            // binKeeperFind(bk, int start, int end) with its clipping (binRange.c:204-206)
-            qs[j] = imax32((int32_t)st[j], 0);
-            qe[j] = imin32((int32_t)en[j], (int32_t)tr[j].y);
-            q[j] = (lut[j] & LUT_OK) && qs[j] < qe[j] && tr[j].z < tr[j].w;
+            derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, tr[j].x, tr[j].y, tr[j].z < tr[j].w, lut[j], st[j], en[j], qs[j], qe[j], q[j],
+                       uq[j]);
             anyq = anyq || q[j];
+        }
+        // ---- cnt[0..7] (generic.c:1048-1055)
+        {
+            const uint32_t n4 = lut[0] + lut[1] + lut[2] + lut[3];                      // 3-bit fields, each <= 4
+            accA += n4 & 0x1c71c7u;
+            accB += (n4 >> 3) & 0x1c71c7u;
+            if (++tiles == 15) {                                                        // 15 * 4 < 64
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[k] += ((accA >> (6 * k)) & 63u) | (((accB >> (6 * k)) & 63u) << 16);
+                accA = accB = tiles = 0;
+            }
         }
         ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + (uint32_t)qs[2] + (uint32_t)qe[3] + lut[0] + lut[1] + lut[2] + lut[3])
 
         // ---- classify
-        int32_t hit[RPL] = {-1, -1, -1, -1};
-        ItxIv rec[RPL];
-#pragma unroll
-        for (int j = 0; j < RPL; j++) rec[j] = ItxIv{0, 0, 0, 0, 0, 0, 0, 0};
         if (__ballot(anyq)) {
             bool fast = uniform;
             uint32_t lo_w = 0, wn = 0, bin_lo = 0;
@@ -291,19 +323,12 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
                     // row says rows below it still end past the query start (pbelow > qs; binRange.c:209-225 without the
                     // bin lists). pbelow only shrinks on the way down and a row that ends at or before qs cannot overlap,
                     // so records that are done just keep stepping, count nothing, and come to rest on the sentinel.
-                    uint32_t kk[RPL], top[RPL];
-                    uint32_t h_k[RPL], h_ov[RPL];                 // the hit found last (lowest row so far)
-                    uint32_t g_k[RPL], g_ov[RPL];                 // the hit found before it
-                    uint32_t nh[RPL];
+                    uint32_t kk[RPL], hk[RPL];        // hk: window entries of the hits so far, one byte each, newest lowest
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        const uint32_t b = (((uint32_t)qe[j] >> T.shift) - bin_lo + 1u) & 63u;
-                        uint32_t h1 = (uint32_t)__shfl((int32_t)bs.x, (int)b, 64);
-                        h1 = h1 > lo_w ? h1 - lo_w : 0u;
-                        h1 = q[j] ? h1 : 0u;
-                        top[j] = kk[j] = h1;                      // rows [0, h1) <=> entries [1, h1]
-                        nh[j] = 0;
-                        h_k[j] = h_ov[j] = g_k[j] = g_ov[j] = 0;
+                        const uint32_t top = top_entry(bs.x, qe[j], T.shift, bin_lo, lo_w);   // a shuffle: every lane takes part
+                        kk[j] = q[j] ? top : 0u;                  // rows [0, top) <=> entries [1, top]
+                        hk[j] = 0;
                     }
                     bool any;
                     do {
@@ -314,57 +339,60 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
                             const int32_t ov = clip_ov((int32_t)v[j].x, (int32_t)v[j].y, qs[j], qe[j]);
-                            const bool ovl = ov > 0;
-                            nh[j] += ovl ? 1u : 0u;
-                            g_k[j] = ovl ? h_k[j] : g_k[j];
-                            g_ov[j] = ovl ? h_ov[j] : g_ov[j];
-                            h_k[j] = ovl ? kk[j] : h_k[j];
-                            h_ov[j] = ovl ? (uint32_t)ov : h_ov[j];
+                            hk[j] = ov > 0 ? (hk[j] << 8) | kk[j] : hk[j];
                             any = any || (int32_t)v[j].z > qs[j];
-                            kk[j] = kk[j] ? kk[j] - 1u : 0u;
+                            kk[j] = __builtin_elementwise_sub_sat(kk[j], 1u);
                         }
                     } while (__ballot(any));
                     // Best hit (generic.c:950-970): in binKeeperFind's list order, the LAST hit whose coverage exceeds the
                     // previous hit's. All hits of a record share the denominator (end - start) and, for overlaps below
                     // 2^23, distinct integer overlaps give distinct f32 quotients — so with two hits the pick is an integer
-                    // comparison on (rank, overlap), and the -c test one multiply (itx_cov_bounds). Three or more hits,
-                    // giant fragments and quotients within 2^-20 of -c replay the reference's arithmetic in full.
-                    bool rare[RPL], anyrare = false;
+                    // comparison on (rank, overlap): the one that comes first in list order stays unless the other overlaps
+                    // more. With one hit the other is the sentinel (negative overlap, last rank) and the same lines hold.
+                    // The -c test is one multiply (itx_cov_bounds). Three or more hits, giant fragments and quotients within
+                    // 2^-20 of -c replay the reference's arithmetic in full.
+                    bool anyrare = false;
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        const uint32_t h_rk = win[2 * h_k[j]].w, g_rk = win[2 * g_k[j]].w;
-                        uint32_t ck, cov_ov;
-                        pick_of_two(nh[j] == 2, h_k[j], h_ov[j], h_rk, g_k[j], g_ov[j], g_rk, &ck, &cov_ov);
+                        const uint32_t h_k = hk[j] & 0xffu, g_k = (hk[j] >> 8) & 0xffu;
+                        const uint4 vh = win[2 * h_k], vg = win[2 * g_k];
+                        const int32_t ov_h = clip_ov((int32_t)vh.x, (int32_t)vh.y, qs[j], qe[j]);
+                        const int32_t ov_g = clip_ov((int32_t)vg.x, (int32_t)vg.y, qs[j], qe[j]);
+                        const bool take_h = ov_h > ov_g || (vh.w < vg.w && ov_h == ov_g);
+                        const uint32_t ck = take_h ? h_k : g_k;
                         const uint32_t qlen = en[j] - st[j];
-                        const bool simple = (nh[j] == 1 || nh[j] == 2) && qlen < (1u << 23);
-                        const float ovf = (float)cov_ov, qf = (float)qlen;
+                        const bool simple = hk[j] != 0 && hk[j] < 0x10000u && qlen < (1u << 23);
+                        const float ovf = (float)imax32(ov_h, ov_g), qf = (float)qlen;
                         const bool pass = ovf >= qf * P.cov_hi, fail = ovf < qf * P.cov_lo;
                         hit[j] = (simple && pass) ? (int32_t)ck : -1;
-                        rare[j] = nh[j] > 0 && !(simple && (pass || fail));
-                        anyrare = anyrare || rare[j];
+                        anyrare = anyrare || (hk[j] != 0 && !(simple && (pass || fail)));
                     }
                     if (__ballot(anyrare)) {
                         IvLds A{win + 2};
+                        uint32_t tops[RPL];
+#pragma unroll
+                        for (int j = 0; j < RPL; j++) tops[j] = top_entry(bs.x, qe[j], T.shift, bin_lo, lo_w);   // every lane takes part
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
-                            if (rare[j]) {
-                                const uint32_t qlen = en[j] - st[j];
-                                if ((nh[j] == 1 || nh[j] == 2) && qlen < (1u << 23)) {
-                                    const uint32_t h_rk = win[2 * h_k[j]].w, g_rk = win[2 * g_k[j]].w;
-                                    uint32_t ck, cov_ov;
-                                    pick_of_two(nh[j] == 2, h_k[j], h_ov[j], h_rk, g_k[j], g_ov[j], g_rk, &ck, &cov_ov);
-                                    const float c = __fdiv_rn((float)cov_ov, (float)qlen);     // generic.c:296-301
-                                    hit[j] = !(c < P.min_cov) ? (int32_t)ck : -1;              // generic.c:961-962
-                                } else {
-                                    uint32_t low = top[j];                                     // rows [low, top) can overlap
-                                    while (low > 0) {
-                                        const int32_t pb = (int32_t)win[2 * low].z;
-                                        low--;
-                                        if (pb <= qs[j]) break;
-                                    }
-                                    const int32_t r = itx_pick_multi(A, low, top[j], qs[j], qe[j], st[j], en[j], P.min_cov);
-                                    hit[j] = r >= 0 ? r + 1 : -1;
+                            const uint32_t qlen = en[j] - st[j];
+                            if (hk[j] != 0 && (hk[j] >= 0x10000u || qlen >= (1u << 23))) {
+                                const uint32_t top = tops[j];
+                                uint32_t low = top;                                        // rows [low, top) can overlap
+                                while (low > 0) {
+                                    const int32_t pb = (int32_t)win[2 * low].z;
+                                    low--;
+                                    if (pb <= qs[j]) break;
                                 }
+                                const int32_t r = itx_pick_multi(A, low, top, qs[j], qe[j], st[j], en[j], P.min_cov);
+                                hit[j] = r >= 0 ? r + 1 : -1;
+                            } else if (hk[j] != 0) {
+                                const uint32_t h_k = hk[j] & 0xffu, g_k = (hk[j] >> 8) & 0xffu;
+                                const uint4 vh = win[2 * h_k], vg = win[2 * g_k];
+                                const int32_t ov_h = clip_ov((int32_t)vh.x, (int32_t)vh.y, qs[j], qe[j]);
+                                const int32_t ov_g = clip_ov((int32_t)vg.x, (int32_t)vg.y, qs[j], qe[j]);
+                                const bool take_h = ov_h > ov_g || (vh.w < vg.w && ov_h == ov_g);
+                                const float c = __fdiv_rn((float)imax32(ov_h, ov_g), (float)qlen);     // generic.c:296-301
+                                hit[j] = !(c < P.min_cov) ? (int32_t)(take_h ? h_k : g_k) : -1;       // generic.c:961-962
                             }
                         }
                     }
@@ -372,46 +400,33 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
                     for (int j = 0; j < RPL; j++) {
                         const uint32_t k = hit[j] >= 0 ? (uint32_t)hit[j] : 0u;
                         const uint4 v0 = win[2 * k], v1 = win[2 * k + 1];
-                        rec[j].s = (int32_t)v0.x; rec[j].e = (int32_t)v0.y; rec[j].pbelow = (int32_t)v0.z; rec[j].rank = v0.w;
-                        rec[j].cs = v1.x; rec[j].jcap = v1.y; rec[j].covslot = v1.z; rec[j].zslot = v1.w;
+                        const ItxIv r = {(int32_t)v0.x, (int32_t)v0.y, (int32_t)v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        uint32_t first;
+                        const uint32_t nc = itx_cov_range(r, st[j], en[j], &first);
+                        hB[j] = hit[j] >= 0 && nc != 0;
+                        sA[j] = hB[j] ? first : r.zslot;
+                        sB[j] = first + nc;
                         hit[j] = hit[j] >= 0 ? hit[j] - 1 + (int32_t)lo_w : -1;
                     }
                     __builtin_amdgcn_wave_barrier();                                    // the window is rewritten next tile
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < RPL; j++) {
-                    if (q[j]) {
-                        hit[j] = itx_classify_lane(T, tr[j].z, bb[j], qs[j], qe[j], st[j], en[j], P.min_cov);
-                        if (hit[j] >= 0) rec[j] = T.iv[hit[j]];
-                    }
-                }
+                for (int j = 0; j < RPL; j++)
+                    if (q[j]) classify_global(T, P, tr[j].z, bb[j], qs[j], qe[j], st[j], en[j], hit[j], sA[j], sB[j], hB[j]);
             }
         }
         ITX_ABLATE_AT(4, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]))
 
-        // ---- cnt[] (generic.c:1048-1060)
+        // ---- hits (generic.c:1030-1032), per wave
         unsigned long long mA[RPL];
-        {
-            const uint32_t n4 = lut[0] + lut[1] + lut[2] + lut[3];                      // 3-bit fields, each <= 4
-            accA += n4 & 0x1c71c7u;
-            accB += (n4 >> 3) & 0x1c71c7u;
-            if (++tiles == 15) {                                                        // 15 * 4 < 64
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    acc[2 * k] += (accA >> (6 * k)) & 63u;
-                    acc[2 * k + 1] += (accB >> (6 * k)) & 63u;
-                }
-                accA = accB = tiles = 0;
-            }
-#pragma unroll
-            for (int j = 0; j < RPL; j++) {
-                mA[j] = __ballot(hit[j] >= 0);                                          // generic.c:1030-1032
-                n_hit += (uint32_t)__popcll(mA[j]);
-                n_hitu += (uint32_t)__popcll(mA[j] & __ballot(uq[j]));
-            }
+        for (int j = 0; j < RPL; j++) {
+            mA[j] = __ballot(hit[j] >= 0);
+            n_hit += (uint32_t)__popcll(mA[j]);
+            n_hitu += (uint32_t)__popcll(mA[j] & __ballot(uq[j]));
         }
-        ITX_ABLATE_AT(5, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]) + accA + n_hit)
+        ITX_ABLATE_AT(5, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]) + n_hit)
 
         // ---- chosen rows back to the caller (row ids as passed to itx_table_create)
         if (d_hit_row) {
@@ -432,18 +447,11 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 if (hit[j] >= 0) {
-                    uint32_t first;
-                    const uint32_t nc = itx_cov_range(rec[j], st[j], en[j], &first);
-                    if (nc) {
-                        atomicAdd(&u32[L.a_all + first], 1u);
-                        atomicAdd(&u32[L.b_all + first + nc], 1u);
-                        if (uq[j]) {
-                            atomicAdd(&u32[L.a_uniq + first], 1u);
-                            atomicAdd(&u32[L.b_uniq + first + nc], 1u);
-                        }
-                    } else {
-                        atomicAdd(&u32[L.a_all + rec[j].zslot], 1u);
-                        if (uq[j]) atomicAdd(&u32[L.a_uniq + rec[j].zslot], 1u);
+                    atomicAdd(&u32[L.a_all + sA[j]], 1u);
+                    if (hB[j]) atomicAdd(&u32[L.b_all + sB[j]], 1u);
+                    if (uq[j]) {
+                        atomicAdd(&u32[L.a_uniq + sA[j]], 1u);
+                        if (hB[j]) atomicAdd(&u32[L.b_uniq + sB[j]], 1u);
                     }
                 }
             }
@@ -456,18 +464,15 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
             }
         } else if (WHAT == ITX_DO_EMIT) {
             uint32_t kA[RPL], kB[RPL];
-            bool hA[RPL], hB[RPL];
+            bool hA[RPL];
             uint32_t total = 0;
             unsigned long long mB[RPL];
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
-                uint32_t first;
-                const uint32_t nc = itx_cov_range(rec[j], st[j], en[j], &first);
                 const uint32_t u = uq[j] ? 1u : 0u;
                 hA[j] = hit[j] >= 0;
-                hB[j] = hA[j] && nc != 0;
-                kA[j] = ((hB[j] ? first : rec[j].zslot) << 2) | u;                     // no coverage: one start in the unit's extra slot
-                kB[j] = ((first + nc) << 2) | 2u | u;
+                kA[j] = (sA[j] << 2) | u;
+                kB[j] = (sB[j] << 2) | 2u | u;
                 mB[j] = __ballot(hB[j]);
                 total += (uint32_t)__popcll(mA[j]) + (uint32_t)__popcll(mB[j]);
             }
@@ -491,14 +496,13 @@ __global__ __launch_bounds__(SB, 4) void k_stream(ItxDevTable T, ItxRunParams P,
     if (sink == 0x7fffff01u) s_cnt[12] = sink;
 #endif
     if (WHAT != ITX_DO_CLASSIFY) {                        // classify-only launches leave every accumulator alone
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            acc[2 * k] += (accA >> (6 * k)) & 63u;
-            acc[2 * k + 1] += (accB >> (6 * k)) & 63u;
-        }
         uint32_t tot[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) tot[k] = wave_sum_u32(acc[k]);
+        for (int k = 0; k < 4; k++) {
+            acc[k] += ((accA >> (6 * k)) & 63u) | (((accB >> (6 * k)) & 63u) << 16);
+            tot[2 * k] = wave_sum_u32(acc[k] & 0xffffu);
+            tot[2 * k + 1] = wave_sum_u32(acc[k] >> 16);
+        }
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -535,8 +539,8 @@ int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, con
         itx_set_error("record arrays must be 16-byte aligned (tid/pos/tmpend/mpos/isize/hit_row) and 4-byte aligned (mapq/flag5)");
         return ITX_E_ARG;
     }
-    if (span % ITX_STREAM_TILE) {
-        itx_set_error("internal: span %zu is not a multiple of %u", span, ITX_STREAM_TILE);
+    if (span % ITX_STREAM_TILE || span > (size_t)16000 * ITX_STREAM_TILE) {         // 16-bit per-lane counters: <= 16383 tiles per wave
+        itx_set_error("internal: span %zu is not a multiple of %u or too long", span, ITX_STREAM_TILE);
         return ITX_E_ARG;
     }
     const dim3 g(n_blocks), b(SB);

@@ -129,6 +129,16 @@ __device__ __forceinline__ void classify_global(const ItxDevTable &T, const ItxR
     }
 }
 
+// Four keys stored at any 4-byte boundary of the key stream with one instruction. The hardware takes unaligned
+// 16-byte global stores (the driver runs gfx9 compute queues in unaligned mode); the compiler, told only "aligned 4",
+// splits them into four, so the instruction is written out.
+typedef uint32_t itx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_key4(uint32_t *dst, const uint4 &k)
+{
+    const itx_u32x4 v = {k.x, k.y, k.z, k.w};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");   // nop: store-data hazard
+}
+
 template <int WHAT>
 __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
                                                int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64,
@@ -155,7 +165,6 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     if (WHAT == ITX_DO_EMIT)
         for (uint32_t k = threadIdx.x; k < E.n_part; k += SB) s_pc[k] = 0;
     __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
     const size_t begin = (size_t)blockIdx.x * span;
     size_t end = begin + span;
     if (end > n) end = n;
@@ -463,32 +472,56 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 if (wave_run((uint32_t)hit[j], hit[j] >= 0, lane, &len, &leader)) atomicAdd(&u32[L.locus + (uint32_t)hit[j]], len);
             }
         } else if (WHAT == ITX_DO_EMIT) {
-            uint32_t kA[RPL], kB[RPL];
-            bool hA[RPL];
-            uint32_t total = 0;
-            unsigned long long mB[RPL];
+            // The tile's keys leave in RECORD order (neighbouring records mostly hit the same row, so the partition path
+            // downstream sees long runs of one partition): every lane drops its up to 8 keys behind those of the lanes
+            // below it in the wave's window — idle at this point — and the wave copies them out 16 bytes per lane.
+            uint32_t *stage = reinterpret_cast<uint32_t *>(win + 2);
+            uint32_t c = 0;
 #pragma unroll
-            for (int j = 0; j < RPL; j++) {
-                const uint32_t u = uq[j] ? 1u : 0u;
-                hA[j] = hit[j] >= 0;
-                kA[j] = (sA[j] << 2) | u;
-                kB[j] = (sB[j] << 2) | 2u | u;
-                mB[j] = __ballot(hB[j]);
-                total += (uint32_t)__popcll(mA[j]) + (uint32_t)__popcll(mB[j]);
-            }
-            uint32_t base = 0;
-            if (lane == 0 && total) base = atomicAdd(&s_cursor, total);          // the workgroup's region cursor (LDS)
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base);
+            for (int j = 0; j < RPL; j++) c += (hit[j] >= 0 ? 1u : 0u) + (hB[j] ? 1u : 0u);
+            uint32_t inc = c;                                                    // inclusive prefix sum over the lanes
+            ITX_DPP_STEP(uadd32, inc, 0, 0x111, 0xf);
+            ITX_DPP_STEP(uadd32, inc, 0, 0x112, 0xf);
+            ITX_DPP_STEP(uadd32, inc, 0, 0x114, 0xf);
+            ITX_DPP_STEP(uadd32, inc, 0, 0x118, 0xf);
+            ITX_DPP_STEP(uadd32, inc, 0, 0x142, 0xa);
+            ITX_DPP_STEP(uadd32, inc, 0, 0x143, 0xc);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int32_t)inc, 63);
+            if (total) {                                                         // wave-uniform
+                uint32_t at = inc - c;
 #pragma unroll
-            for (int j = 0; j < RPL; j++) {
-                if (hA[j]) out[base + (uint32_t)__popcll(mA[j] & lt)] = kA[j];
-                base += (uint32_t)__popcll(mA[j]);
-                if (hB[j]) out[base + (uint32_t)__popcll(mB[j] & lt)] = kB[j];
-                base += (uint32_t)__popcll(mB[j]);
-                // keys per partition of this workgroup's region (LDS adds to equal addresses serialise in the LDS
-                // pipeline, beside the VALU work, which is what bounds this kernel)
-                if (hA[j]) atomicAdd(&s_pc[kA[j] >> (2 + E.log_w)], 1u);
-                if (hB[j]) atomicAdd(&s_pc[kB[j] >> (2 + E.log_w)], 1u);
+                for (int j = 0; j < RPL; j++) {
+                    const uint32_t u = uq[j] ? 1u : 0u;
+                    if (hit[j] >= 0) stage[at] = (sA[j] << 2) | u;
+                    at += hit[j] >= 0 ? 1u : 0u;
+                    if (hB[j]) stage[at] = (sB[j] << 2) | 2u | u;
+                    at += hB[j] ? 1u : 0u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_cursor, total);               // the workgroup's region cursor (LDS)
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base);
+                const uint32_t sh = 2 + E.log_w;
+                for (uint32_t i = 4 * lane; i < total; i += 4 * 64) {
+                    const uint4 k4 = *reinterpret_cast<const uint4 *>(stage + i);
+                    const uint32_t m = total - i;                                // keys of this piece that exist (>= 1)
+                    uint32_t *dst = out + base + i;
+                    if (m >= 4) {
+                        store_key4(dst, k4);
+                    } else {
+                        dst[0] = k4.x;
+                        if (m > 1) dst[1] = k4.y;
+                        if (m > 2) dst[2] = k4.z;
+                    }
+                    // keys per partition of this workgroup's region
+                    atomicAdd(&s_pc[k4.x >> sh], 1u);
+                    if (m > 1) atomicAdd(&s_pc[k4.y >> sh], 1u);
+                    if (m > 2) atomicAdd(&s_pc[k4.z >> sh], 1u);
+                    if (m > 3) atomicAdd(&s_pc[k4.w >> sh], 1u);
+                }
+                __builtin_amdgcn_wave_barrier();                                 // the window is rewritten next tile
             }
         }
     }

@@ -150,6 +150,10 @@ struct ItxDevBatch {
 // Streaming kernel (itx_stream.hip): one launch classifies n records and, per `what`, does nothing else,
 // accumulates with global atomics (stat: A/B arrays, filter: per-locus counts) or emits keys.
 enum { ITX_DO_CLASSIFY = 0, ITX_DO_ATOMIC_STAT = 1, ITX_DO_ATOMIC_LOCUS = 2, ITX_DO_EMIT = 3 };
+#define ITX_STREAM_LB 5             // workgroups of the streaming kernel per CU its register budget is set for (96 VGPRs)
+// Workgroups of a streaming launch: one full wave of the chip (CUs x ITX_STREAM_LB), each walking one contiguous
+// span of records; ITX_STREAM_BLOCKS overrides (experiments), 2048 bounds the per-region bookkeeping.
+unsigned itx_stream_blocks(int device);
 #define ITX_STREAM_TILE 1024u      // records per workgroup iteration (4 waves x 64 lanes x 4 records)
 #define ITX_PART_SUB 8u            // sub-cursors per partition (partition path)
 // What the emitting launch needs to know about the partition path's bookkeeping.

@@ -62,7 +62,7 @@ struct IvLds {
 // binKeeperFind returns them (list-order rank) and keep the LAST one whose coverage exceeds its predecessor's.
 // Returns the chosen candidate or -1 (also when its coverage is below min_cov, generic.c:961-962).
 template <class ACC>
-__device__ __noinline__ int32_t itx_pick_multi(const ACC &A, uint32_t low, uint32_t hi, int32_t qs, int32_t qe, uint32_t ustart,
+__device__ __forceinline__ int32_t itx_pick_multi(const ACC &A, uint32_t low, uint32_t hi, int32_t qs, int32_t qe, uint32_t ustart,
                                                uint32_t uend, float min_cov)
 {
     int64_t best_rank = -1;

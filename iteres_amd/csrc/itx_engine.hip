@@ -98,11 +98,7 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     e->records = e->submits = e->keys = 0;
     memset(e->stage_ms, 0, sizeof e->stage_ms);
     e->pw = nullptr;
-    e->max_blocks = 2048;
-    if (const char *s = getenv("ITX_STREAM_BLOCKS")) {
-        const long v = atol(s);
-        if (v >= 1 && v <= 2048) e->max_blocks = (unsigned)v;
-    }
+    e->max_blocks = itx_stream_blocks(t->device);
     hipError_t he = hipMalloc((void **)&e->u64, 16 * sizeof(uint64_t));
     if (he == hipSuccess) he = hipMemset(e->u64, 0, 16 * sizeof(uint64_t));
     if (he == hipSuccess) he = hipMalloc((void **)&e->u32, (e->L.n_u32 + 4) * sizeof(uint32_t));

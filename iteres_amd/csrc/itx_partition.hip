@@ -64,11 +64,7 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
     ItxPartWork *w = new ItxPartWork();
     w->cap = cap;
     w->n_part = n_part ? n_part : 1;
-    w->max_blocks = 2048;
-    if (const char *s = getenv("ITX_STREAM_BLOCKS")) {
-        const long v = atol(s);
-        if (v >= 1 && v <= 2048) w->max_blocks = (uint32_t)v;
-    }
+    w->max_blocks = itx_stream_blocks(t->device);
     w->max_items = w->n_part + (uint32_t)((2 * cap) / ITX_CHUNK) + 2;
     const size_t kcap = 2 * (cap + ITX_STREAM_TILE) * 4 + 64;
     size_t off = 0;

@@ -19,10 +19,11 @@
 // and nested divergent branches cost more exec-mask bookkeeping than the arithmetic they skip.
 // No MFMA: the path is integer compares and one f32 ratio; the roofline that bounds it is HBM.
 #include "itx_device.h"
+#include <stdlib.h>
 
 #define SB 256
 #ifndef ITX_LB
-#define ITX_LB 4          // workgroups per CU the register budget is set for
+#define ITX_LB ITX_STREAM_LB
 #endif
 #define RPL 4
 #define WTILE (64 * RPL)
@@ -247,38 +248,40 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         }
         const bool uniform = __ballot(!same) == 0ull;
 
-        // ---- derive (generic.c:748-922): flag logic from the table, coordinates predicated
-        uint32_t lut[RPL], st[RPL], en[RPL];       // st/en: the reference's unsigned start/end
-        int32_t qs[RPL], qe[RPL];
+        // ---- derive (generic.c:748-922): flag logic from the table, coordinates predicated, the reference's record in
+        // scalar registers. A tile that straddles references (a handful per sorted file), or holds a record whose
+        // unsigned start/end differ from the clipped query binKeeperFind sees (negative positions), is taken record by
+        // record straight away — own reference record, lookup in global memory — while the raw fields are at hand.
+        uint32_t lut[RPL];
+        int32_t qs[RPL], qe[RPL];                  // for every record that goes on: also the reference's start / end
         bool q[RPL], uq[RPL];
-        bool anyq = false;
+        bool anyq = false, odd = !uniform;
         int32_t hit[RPL] = {-1, -1, -1, -1};
         uint32_t sA[RPL] = {0, 0, 0, 0}, sB[RPL] = {0, 0, 0, 0};  // slots of the start / end marks of the chosen row's consensus range
         bool hB[RPL] = {false, false, false, false};              // the read adds coverage (else: one start in the unit's extra slot)
-        uint4 tr[RPL];
-        uint32_t bb[RPL];
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            tr[j] = cur0;
-            bb[j] = cur_bb;
+            uint32_t st, en;
+            derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, cur0.x, cur0.y, cur0.z < cur0.w, lut[j], st, en, qs[j], qe[j], q[j], uq[j]);
+            odd = odd || (q[j] && ((int32_t)st != qs[j] || (int32_t)en != qe[j]));
+            anyq = anyq || q[j];
         }
-        if (!uniform) {                                                         // mixed references in one tile: rare
+        if (__ballot(odd)) {                                                    // rare
+            anyq = false;
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 const int32_t t = raw[j].tid;
+                uint4 tr = make_uint4(0xffffffffu, 0, 0, 0);
+                uint32_t bb = 0;
                 if (ex[j] && t >= 0 && t < P.n_tid) {
-                    tr[j] = *reinterpret_cast<const uint4 *>(&P.tidrec[t]);
-                    bb[j] = P.tidrec[t].bin_base;
-                } else {
-                    tr[j] = make_uint4(0xffffffffu, 0, 0, 0);
+                    tr = *reinterpret_cast<const uint4 *>(&P.tidrec[t]);
+                    bb = P.tidrec[t].bin_base;
                 }
+                uint32_t st, en;
+                derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, tr.x, tr.y, tr.z < tr.w, lut[j], st, en, qs[j], qe[j], q[j], uq[j]);
+                if (q[j]) classify_global(T, P, tr.z, bb, qs[j], qe[j], st, en, hit[j], sA[j], sB[j], hB[j]);
+                q[j] = false;
             }
-        }
-#pragma unroll
-        for (int j = 0; j < RPL; j++) {
-            derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, tr[j].x, tr[j].y, tr[j].z < tr[j].w, lut[j], st[j], en[j], qs[j], qe[j], q[j],
-                       uq[j]);
-            anyq = anyq || q[j];
         }
         // ---- cnt[0..7] (generic.c:1048-1055)
         {
@@ -291,32 +294,29 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 accA = accB = tiles = 0;
             }
         }
-        ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + (uint32_t)qs[2] + (uint32_t)qe[3] + lut[0] + lut[1] + lut[2] + lut[3])
+        ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + (uint32_t)qs[2] + (uint32_t)qe[3] + accA + accB)
 
-        // ---- classify
+        // ---- classify: every record left is on the cached reference
         if (__ballot(anyq)) {
-            bool fast = uniform;
-            uint32_t lo_w = 0, wn = 0, bin_lo = 0;
+            uint32_t lo_w = 0, wn = 0;
             uint2 bs = make_uint2(0, 0);
-            if (fast) {
-                int32_t mn = 0x7fffffff, mx = 0;
+            int32_t mn = 0x7fffffff, mx = 0;
 #pragma unroll
-                for (int j = 0; j < RPL; j++) {
-                    mn = q[j] ? imin32(qs[j], mn) : mn;
-                    mx = q[j] ? imax32(qe[j], mx) : mx;
-                }
-                mn = wave_min_i32(mn);
-                mx = wave_max_i32(mx);
-                bin_lo = (uint32_t)mn >> T.shift;
-                const uint32_t nb = ((uint32_t)mx >> T.shift) + 1 - bin_lo + 1;     // bins bin_lo .. bin(mx)+1
-                fast = nb <= 64;
-                if (fast) {
-                    if (lane < nb) bs = T.bl[cur_bb + bin_lo + lane];
-                    lo_w = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)bs.y);
-                    const uint32_t hi_w = (uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, (int)(nb - 1));
-                    wn = hi_w > lo_w ? hi_w - lo_w : 0u;
-                    fast = wn <= ITX_WIN;
-                }
+            for (int j = 0; j < RPL; j++) {
+                mn = q[j] ? imin32(qs[j], mn) : mn;
+                mx = q[j] ? imax32(qe[j], mx) : mx;
+            }
+            mn = wave_min_i32(mn);
+            mx = wave_max_i32(mx);
+            const uint32_t bin_lo = (uint32_t)mn >> T.shift;
+            const uint32_t nb = ((uint32_t)mx >> T.shift) + 1 - bin_lo + 1;         // bins bin_lo .. bin(mx)+1
+            bool fast = nb <= 64;
+            if (fast) {
+                if (lane < nb) bs = T.bl[cur_bb + bin_lo + lane];
+                lo_w = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)bs.y);
+                const uint32_t hi_w = (uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, (int)(nb - 1));
+                wn = hi_w > lo_w ? hi_w - lo_w : 0u;
+                fast = wn <= ITX_WIN;
             }
             if (fast) {
                 if (wn) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                         const int32_t ov_g = clip_ov((int32_t)vg.x, (int32_t)vg.y, qs[j], qe[j]);
                         const bool take_h = ov_h > ov_g || (vh.w < vg.w && ov_h == ov_g);
                         const uint32_t ck = take_h ? h_k : g_k;
-                        const uint32_t qlen = en[j] - st[j];
+                        const uint32_t qlen = (uint32_t)qe[j] - (uint32_t)qs[j];
                         const bool simple = hk[j] != 0 && hk[j] < 0x10000u && qlen < (1u << 23);
                         const float ovf = (float)imax32(ov_h, ov_g), qf = (float)qlen;
                         const bool pass = ovf >= qf * P.cov_hi, fail = ovf < qf * P.cov_lo;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                         for (int j = 0; j < RPL; j++) tops[j] = top_entry(bs.x, qe[j], T.shift, bin_lo, lo_w);   // every lane takes part
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
-                            const uint32_t qlen = en[j] - st[j];
+                            const uint32_t qlen = (uint32_t)qe[j] - (uint32_t)qs[j];
                             if (hk[j] != 0 && (hk[j] >= 0x10000u || qlen >= (1u << 23))) {
                                 const uint32_t top = tops[j];
                                 uint32_t low = top;                                        // rows [low, top) can overlap
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                                     low--;
                                     if (pb <= qs[j]) break;
                                 }
-                                const int32_t r = itx_pick_multi(A, low, top, qs[j], qe[j], st[j], en[j], P.min_cov);
+                                const int32_t r = itx_pick_multi(A, low, top, qs[j], qe[j], (uint32_t)qs[j], (uint32_t)qe[j], P.min_cov);
                                 hit[j] = r >= 0 ? r + 1 : -1;
                             } else if (hk[j] != 0) {
                                 const uint32_t h_k = hk[j] & 0xffu, g_k = (hk[j] >> 8) & 0xffu;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                         const uint4 v0 = win[2 * k], v1 = win[2 * k + 1];
                         const ItxIv r = {(int32_t)v0.x, (int32_t)v0.y, (int32_t)v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                         uint32_t first;
-                        const uint32_t nc = itx_cov_range(r, st[j], en[j], &first);
+                        const uint32_t nc = itx_cov_range(r, (uint32_t)qs[j], (uint32_t)qe[j], &first);
                         hB[j] = hit[j] >= 0 && nc != 0;
                         sA[j] = hB[j] ? first : r.zslot;
                         sB[j] = first + nc;
@@ -419,10 +419,10 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                     }
                     __builtin_amdgcn_wave_barrier();                                    // the window is rewritten next tile
                 }
-            } else {
+            } else {                                                            // sparse or unsorted records: global lookups
 #pragma unroll
                 for (int j = 0; j < RPL; j++)
-                    if (q[j]) classify_global(T, P, tr[j].z, bb[j], qs[j], qe[j], st[j], en[j], hit[j], sA[j], sB[j], hB[j]);
+                    if (q[j]) classify_global(T, P, cur0.z, cur_bb, qs[j], qe[j], (uint32_t)qs[j], (uint32_t)qe[j], hit[j], sA[j], sB[j], hB[j]);
             }
         }
         ITX_ABLATE_AT(4, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]))
@@ -560,6 +560,18 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             row[k] = c ? atomicAdd(&E.subcur[k * ITX_PART_SUB + sub], c) : 0u;
         }
     }
+}
+
+unsigned itx_stream_blocks(int device)
+{
+    if (const char *s = getenv("ITX_STREAM_BLOCKS")) {
+        const long v = atol(s);
+        if (v >= 1 && v <= 2048) return (unsigned)v;
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    const unsigned b = (unsigned)cus * ITX_LB;
+    return b > 2048u ? 2048u : b;
 }
 
 int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, size_t span,

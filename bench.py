@@ -127,10 +127,10 @@ def main():
         value = total_reads / elapsed / 1e6
         stream_ms = st["stage_ms"][0] / max(st["submits"], 1)
         keys = st["keys"]
-        # algorithmic bytes of one k_stream launch: 14 B per record in, 4 B per key out,
+        # algorithmic bytes of one k_stream launch: 14 B per record in, 8 B per key out,
         # plus the table rows (32 B) and binned index (8 B/bin) once per launch
         table_once = int(table.info.n_rows) * 32 + int(sum(s for _, s in chroms) >> int(table.info.bin_shift)) * 8
-        alg_bytes = 14 * a.reads + 4 * keys + table_once
+        alg_bytes = 14 * a.reads + 8 * keys + table_once
         achieved = alg_bytes / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")

@@ -164,7 +164,7 @@ struct ItxEmitPlan {
     uint32_t log_w;     // log2(slots per partition)
 };
 int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, size_t span,
-                      unsigned n_blocks, int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, uint32_t *keys0,
+                      unsigned n_blocks, int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, uint2 *keys0,
                       uint32_t *blk_cnt, const ItxEmitPlan &E, hipStream_t st);
 // finish-time kernels (itx_finalize.hip)
 int itx_launch_export(const itx_table *t, int mode, const uint64_t *u64, const uint32_t *u32, const ItxAccumLayout &L, uint64_t *p64,

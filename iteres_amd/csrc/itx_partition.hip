@@ -5,8 +5,10 @@
 // global atomics it costs one memory-side atomic request per key (measured ~9 G/s on MI355X: 10x the
 // rest of the path). Here the transposition is done the radix way:
 //
-//   A  k_stream<EMIT> (itx_stream.hip)  1-2 keys per classified record (slot<<2 | isEnd<<1 | uniq),
-//                  written compacted into the workgroup's own region (LDS cursor, no global atomic).
+//   A  k_stream<EMIT> (itx_stream.hip)  one 8-byte key per classified record — (type | uniq<<2 | len<<3, slot): a
+//                  start mark at slot and an end mark at slot+len — or two when the marks fall into different
+//                  partitions, written compacted in record order into the workgroup's own region (LDS cursor, no
+//                  global atomic).
 //   C  (inside A)  per workgroup region: per-partition key counts (run lengths per wave — sorted input
 //                  gives long runs — into an LDS histogram), then ONE reservation per touched partition on
 //                  one of 8 sub-cursors (workgroup id mod 8: the dispatcher deals workgroups round-robin over
@@ -15,7 +17,8 @@
 //   S  k_plan      one workgroup: exclusive scan of the 8*P sub-totals -> bases, and the work list of
 //                  (partition, key range) items for H (a partition with more than ITX_CHUNK keys is split).
 //   P  k_scatter   per region: cursor[p] = base[p][sub] + offset row in LDS, then every run of equal partitions
-//                  takes its places with one returning LDS add and writes its keys — no global atomics.
+//                  takes its places with one returning LDS add and writes its keys, now 4 bytes each (slot within
+//                  the partition << 16 | low half of the 8-byte key) — no global atomics.
 //   H  k_hist      per item: LDS window of the partition's W slots (A|B counts, all:16|uniq:16 packed),
 //                  ds_add per key, then the window is added into the global A/B arrays — plain
 //                  coalesced read-modify-write when the item owns its partition, atomics (few: the
@@ -40,7 +43,8 @@ struct ItxPartWork {
     uint32_t n_part;       // partitions
     uint32_t max_blocks;   // workgroups of the emit launch (regions are per workgroup)
     uint32_t max_items;
-    uint32_t *keys0, *keys1;   // [2*cap]
+    uint2 *keys0;              // [2*cap] 8-byte keys as emitted, per workgroup region
+    uint32_t *keys1;           // [2*cap] 4-byte keys, partitioned
     uint32_t *blk_cnt;         // [max_blocks] keys emitted by each workgroup
     uint32_t *subcur;          // [n_part*8] sub-totals, then (after k_plan) bases
     uint32_t *offm;            // [max_blocks][n_part] offset of each region inside (partition, sub)
@@ -68,7 +72,7 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
     w->max_items = w->n_part + (uint32_t)((2 * cap) / ITX_CHUNK) + 2;
     const size_t kcap = 2 * (cap + ITX_STREAM_TILE) * 4 + 64;
     size_t off = 0;
-    const size_t o_k0 = off; off = al256(off + kcap);
+    const size_t o_k0 = off; off = al256(off + 2 * kcap);
     const size_t o_k1 = off; off = al256(off + kcap);
     const size_t o_bc = off; off = al256(off + (size_t)w->max_blocks * 4);
     const size_t o_sc = off; off = al256(off + ((size_t)w->n_part * ITX_SUB + 1) * 4);
@@ -83,7 +87,7 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
         return ITX_E_NOMEM;
     }
     w->base = base;
-    w->keys0 = (uint32_t *)(base + o_k0);
+    w->keys0 = (uint2 *)(base + o_k0);
     w->keys1 = (uint32_t *)(base + o_k1);
     w->blk_cnt = (uint32_t *)(base + o_bc);
     w->subcur = (uint32_t *)(base + o_sc);
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(1024) void k_plan(uint32_t *__restrict__ subcur, ui
 }
 
 // ------------------------------------------------------------------------------------------------ P
-__global__ __launch_bounds__(PB) void k_scatter(const uint32_t *__restrict__ keys0, const uint32_t *__restrict__ blk_cnt, size_t span,
+__global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0, const uint32_t *__restrict__ blk_cnt, size_t span,
                                                 const uint32_t *__restrict__ subcur, const uint32_t *__restrict__ offm,
                                                 uint32_t *__restrict__ keys1, uint32_t n_part)
 {
@@ -162,28 +166,28 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint32_t *__restrict__ key
     for (uint32_t k = threadIdx.x; k < n_part; k += PB) s_cur[k] = subcur[k * ITX_SUB + sub] + row[k];
     __syncthreads();
     const uint32_t total = blk_cnt[blockIdx.x];
-    const uint32_t *in = keys0 + 2 * (size_t)blockIdx.x * span;
+    const uint2 *in = keys0 + 2 * (size_t)blockIdx.x * span;
     const uint32_t lane = threadIdx.x & 63u;
     // 8 rounds of 256 keys per iteration: the loads of all eight are in flight before the first is used
     // (one round after the other leaves the kernel waiting on one global load per 256 keys per workgroup)
     constexpr int U = 8;
     for (uint32_t r0 = 0; r0 < total; r0 += U * PB) {
-        uint32_t key[U];
+        uint2 key[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t idx = r0 + u * PB + threadIdx.x;
-            key[u] = idx < total ? in[idx] : 0xffffffffu;
+            key[u] = idx < total ? in[idx] : make_uint2(0, 0xffffffffu);
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const bool has = key[u] != 0xffffffffu;
-            const uint32_t p = has ? key[u] >> (2 + ITX_LOGW) : 0xffffffffu;
+            const bool has = key[u].y != 0xffffffffu;
+            const uint32_t p = has ? key[u].y >> ITX_LOGW : 0xffffffffu;
             uint32_t len, leader;
             const bool st = wave_run(p, has, lane, &len, &leader);
             uint32_t base = 0;
             if (st) base = atomicAdd(&s_cur[p], len);             // one returning LDS add per run
             base = (uint32_t)__shfl((int32_t)base, (int)leader, 64);
-            if (has) keys1[base + (lane - leader)] = key[u];
+            if (has) keys1[base + (lane - leader)] = ((key[u].y & (ITX_W - 1)) << 16) | (key[u].x & 0xffffu);
         }
     }
 }
@@ -213,9 +217,10 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (key[u] != 0xffffffffu) {
-                    const uint32_t sl = (key[u] >> 2) - slot0;
-                    const uint32_t v = 1u | ((key[u] & 1u) << 16);
-                    if (key[u] & 2u) atomicAdd(&s_b[sl], v); else atomicAdd(&s_a[sl], v);
+                    const uint32_t sl = key[u] >> 16, type = key[u] & 3u, len = (key[u] >> 3) & (ITX_W - 1);
+                    const uint32_t v = 1u | ((key[u] & 4u) << 14);
+                    if (type != 2u) atomicAdd(&s_a[sl], v);                      // start mark
+                    if (type != 1u) atomicAdd(&s_b[sl + len], v);                // end mark (len == 0 for type 2)
                 }
             }
         }

@@ -130,7 +130,7 @@ __device__ __forceinline__ void classify_global(const ItxDevTable &T, const ItxR
     }
 }
 
-// Four keys stored at any 4-byte boundary of the key stream with one instruction. The hardware takes unaligned
+// Sixteen bytes of keys stored at any 4-byte boundary of the key stream with one instruction. The hardware takes unaligned
 // 16-byte global stores (the driver runs gfx9 compute queues in unaligned mode); the compiler, told only "aligned 4",
 // splits them into four, so the instruction is written out.
 typedef uint32_t itx_u32x4 __attribute__((ext_vector_type(4)));
@@ -143,7 +143,7 @@ __device__ __forceinline__ void store_key4(uint32_t *dst, const uint4 &k)
 template <int WHAT>
 __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
                                                int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64,
-                                               uint32_t *__restrict__ u32, ItxAccumLayout L, uint32_t *__restrict__ keys0,
+                                               uint32_t *__restrict__ u32, ItxAccumLayout L, uint2 *__restrict__ keys0,
                                                uint32_t *__restrict__ blk_cnt, ItxEmitPlan E)
 {
     // a wave's window: entry 0 is a sentinel no query overlaps and no scan walks past, table row lo_w + i sits at entry i + 1
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     const size_t begin = (size_t)blockIdx.x * span;
     size_t end = begin + span;
     if (end > n) end = n;
-    uint32_t *out = keys0 ? keys0 + 2 * begin : nullptr;
+    uint2 *out = keys0 ? keys0 + 2 * begin : nullptr;       // at most two keys per record
     const bool have_pe = B.isize != nullptr;
 
     // wave-uniform cache of the current reference's ItxTidRec
@@ -472,13 +472,21 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 if (wave_run((uint32_t)hit[j], hit[j] >= 0, lane, &len, &leader)) atomicAdd(&u32[L.locus + (uint32_t)hit[j]], len);
             }
         } else if (WHAT == ITX_DO_EMIT) {
-            // The tile's keys leave in RECORD order (neighbouring records mostly hit the same row, so the partition path
-            // downstream sees long runs of one partition): every lane drops its up to 8 keys behind those of the lanes
+            // One 8-byte key per classified record: low word = type | uniq << 2 | len << 3, high word = slot.
+            //   type 0: a start mark at slot and an end mark at slot + len (both inside one partition, len < 2^13)
+            //   type 1: a start mark only (the read adds no coverage, or its end mark lies in another partition)
+            //   type 2: an end mark only (the other half of such a read)
+            // The tile's keys leave in RECORD order (neighbouring records mostly hit the same row, so the partition
+            // path downstream sees long runs of one partition): every lane drops its keys behind those of the lanes
             // below it in the wave's window — idle at this point — and the wave copies them out 16 bytes per lane.
-            uint32_t *stage = reinterpret_cast<uint32_t *>(win + 2);
+            uint2 *stage = reinterpret_cast<uint2 *>(win + 2);
+            bool two[RPL];
             uint32_t c = 0;
 #pragma unroll
-            for (int j = 0; j < RPL; j++) c += (hit[j] >= 0 ? 1u : 0u) + (hB[j] ? 1u : 0u);
+            for (int j = 0; j < RPL; j++) {
+                two[j] = hB[j] && (sA[j] >> E.log_w) != (sB[j] >> E.log_w);
+                c += (hit[j] >= 0 ? 1u : 0u) + (two[j] ? 1u : 0u);
+            }
             uint32_t inc = c;                                                    // inclusive prefix sum over the lanes
             ITX_DPP_STEP(uadd32, inc, 0, 0x111, 0xf);
             ITX_DPP_STEP(uadd32, inc, 0, 0x112, 0xf);
@@ -491,11 +499,12 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 uint32_t at = inc - c;
 #pragma unroll
                 for (int j = 0; j < RPL; j++) {
-                    const uint32_t u = uq[j] ? 1u : 0u;
-                    if (hit[j] >= 0) stage[at] = (sA[j] << 2) | u;
+                    const uint32_t u = uq[j] ? 4u : 0u;
+                    const uint32_t lo = (hB[j] && !two[j]) ? (((sB[j] - sA[j]) << 3) | u) : (1u | u);
+                    if (hit[j] >= 0) stage[at] = make_uint2(lo, sA[j]);
                     at += hit[j] >= 0 ? 1u : 0u;
-                    if (hB[j]) stage[at] = (sB[j] << 2) | 2u | u;
-                    at += hB[j] ? 1u : 0u;
+                    if (two[j]) stage[at] = make_uint2(2u | u, sB[j]);
+                    at += two[j] ? 1u : 0u;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -503,23 +512,16 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&s_cursor, total);               // the workgroup's region cursor (LDS)
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base);
-                const uint32_t sh = 2 + E.log_w;
-                for (uint32_t i = 4 * lane; i < total; i += 4 * 64) {
-                    const uint4 k4 = *reinterpret_cast<const uint4 *>(stage + i);
-                    const uint32_t m = total - i;                                // keys of this piece that exist (>= 1)
-                    uint32_t *dst = out + base + i;
-                    if (m >= 4) {
-                        store_key4(dst, k4);
+                for (uint32_t i = 2 * lane; i < total; i += 2 * 64) {
+                    const uint4 k2 = *reinterpret_cast<const uint4 *>(stage + i);        // two keys
+                    uint2 *dst = out + base + i;
+                    if (total - i >= 2) {
+                        store_key4(reinterpret_cast<uint32_t *>(dst), k2);
+                        atomicAdd(&s_pc[k2.w >> E.log_w], 1u);
                     } else {
-                        dst[0] = k4.x;
-                        if (m > 1) dst[1] = k4.y;
-                        if (m > 2) dst[2] = k4.z;
+                        dst[0] = make_uint2(k2.x, k2.y);
                     }
-                    // keys per partition of this workgroup's region
-                    atomicAdd(&s_pc[k4.x >> sh], 1u);
-                    if (m > 1) atomicAdd(&s_pc[k4.y >> sh], 1u);
-                    if (m > 2) atomicAdd(&s_pc[k4.z >> sh], 1u);
-                    if (m > 3) atomicAdd(&s_pc[k4.w >> sh], 1u);
+                    atomicAdd(&s_pc[k2.y >> E.log_w], 1u);                       // keys per partition of this workgroup's region
                 }
                 __builtin_amdgcn_wave_barrier();                                 // the window is rewritten next tile
             }
@@ -575,7 +577,7 @@ unsigned itx_stream_blocks(int device)
 }
 
 int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, size_t span,
-                      unsigned n_blocks, int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, uint32_t *keys0,
+                      unsigned n_blocks, int32_t *d_hit_row, uint64_t *u64, uint32_t *u32, const ItxAccumLayout &L, uint2 *keys0,
                       uint32_t *blk_cnt, const ItxEmitPlan &E, hipStream_t st)
 {
     if (n == 0) return ITX_OK;

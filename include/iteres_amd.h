@@ -107,7 +107,11 @@ typedef struct itx_params {
  *   tid, pos            bam1_core_t.tid / .pos                       (cussamtools/bam.h:169-177)
  *   tmpend              n_cigar ? bam_calend(core, cigar) : pos + l_qseq          (generic.c:820)
  *   mapq                bam1_core_t.qual
- *   flag5               bit0 PAIRED(0x1) bit1 UNMAP(0x4) bit2 MUNMAP(0x8) bit3 REVERSE(0x10) bit4 READ1(0x40)
+ *   flag5               bit0 PAIRED(0x1) bit1 UNMAP(0x4) bit2 MUNMAP(0x8) bit3 REVERSE(0x10) bit4 READ1(0x40);
+ *                       bit5 ITX_F5_NOLOOKUP, set by the caller: the record is counted like any other up to
+ *                       reads_mapped / reads_mapped_unique (cnt[0..7], cnt[11]) but is not looked up — how a caller
+ *                       applies the reference's two `continue`s that sit between those counters and the
+ *                       accumulation: -R duplicates (generic.c:907-919) and the XA veto (generic.c:972-982)
  *   mpos, isize         bam1_core_t.mpos / .isize; both may be NULL when no record of the batch
  *                       has PAIRED set (then they are never read). */
 typedef struct itx_batch {
@@ -115,6 +119,7 @@ typedef struct itx_batch {
     const uint8_t *mapq, *flag5;
     const int32_t *mpos, *isize;
 } itx_batch;
+#define ITX_F5_NOLOOKUP 0x20
 #define ITX_FLAG5(bamflag) ((uint8_t)((((bamflag) & 0x1) ? 1 : 0) | (((bamflag) & 0x4) ? 2 : 0) | (((bamflag) & 0x8) ? 4 : 0) | \
                                       (((bamflag) & 0x10) ? 8 : 0) | (((bamflag) & 0x40) ? 16 : 0)))
 
@@ -140,6 +145,10 @@ int itx_engine_staging(itx_engine *e, int slot, itx_staging *out);
  * has PAIRED set (mpos/isize are then not copied). want_hits: write back per record the index of
  * the chosen table row (as passed to itx_table_create) or -1 into staging.hit_row. */
 int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has_paired, int want_hits);
+/* Same copies, classification only: nothing is accumulated, staging.hit_row receives the chosen rows. For
+ * callers that must look at the chosen row before the record counts (the XA veto): classify, wait, set
+ * ITX_F5_NOLOOKUP on the vetoed records, then submit the slot. */
+int itx_engine_classify_slot(itx_engine *e, int slot, size_t n, int has_paired);
 int itx_engine_wait_slot(itx_engine *e, int slot);
 
 /* Same work on a batch that is ALREADY in device memory (pointers in `b` are device pointers, each

@@ -9,6 +9,7 @@
 #define F5_MUNMAP 4u
 #define F5_REVERSE 8u
 #define F5_READ1 16u
+#define F5_NOLOOKUP 32u
 
 #define ITX_WIN 128          // intervals a wave stages in LDS for its tile of records (ItxIv each)
 

@@ -283,10 +283,10 @@ static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_h
     return rc;
 }
 
-extern "C" int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has_paired, int want_hits)
+static int slot_run(itx_engine *e, int slot, size_t n, int has_paired, int want_hits, bool accumulate)
 {
     if (!e || slot < 0 || slot > 1) {
-        itx_set_error("itx_engine_submit_slot: bad argument");
+        itx_set_error("itx_engine_submit/classify_slot: bad argument");
         return ITX_E_ARG;
     }
     int rc = use_device(e);
@@ -294,7 +294,7 @@ extern "C" int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has
     rc = ensure_slots(e);
     if (rc) return rc;
     if (n > e->cap) {
-        itx_set_error("itx_engine_submit_slot: %zu records exceed the slot capacity %zu", n, e->cap);
+        itx_set_error("itx_engine_submit/classify_slot: %zu records exceed the slot capacity %zu", n, e->cap);
         return ITX_E_ARG;
     }
     ItxSlot &S = e->slot[slot];
@@ -314,7 +314,7 @@ extern "C" int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has
                      has_paired ? S.d.isize : nullptr};
     ITX_HIP(hipEventRecord(S.copied, S.stream));
     ITX_HIP(hipStreamWaitEvent(e->compute, S.copied, 0));
-    rc = run_batch(e, B, n, want_hits ? S.d.hit_row : nullptr, e->compute, true);
+    rc = run_batch(e, B, n, want_hits ? S.d.hit_row : nullptr, e->compute, accumulate);
     if (rc) return rc;
     ITX_HIP(hipEventRecord(S.done, e->compute));
     ITX_HIP(hipStreamWaitEvent(S.stream, S.done, 0));
@@ -322,6 +322,16 @@ extern "C" int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has
         ITX_HIP(hipMemcpyAsync(S.h.hit_row, S.d.hit_row, n * sizeof(int32_t), hipMemcpyDeviceToHost, S.stream));
     S.busy = true;
     return ITX_OK;
+}
+
+extern "C" int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has_paired, int want_hits)
+{
+    return slot_run(e, slot, n, has_paired, want_hits, true);
+}
+
+extern "C" int itx_engine_classify_slot(itx_engine *e, int slot, size_t n, int has_paired)
+{
+    return slot_run(e, slot, n, has_paired, 1, false);
 }
 
 extern "C" int itx_engine_wait_slot(itx_engine *e, int slot)

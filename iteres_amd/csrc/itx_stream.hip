@@ -29,15 +29,15 @@
 #define WTILE (64 * RPL)
 
 // Everything generic.c:748-922 decides from a record's flag bits alone, tabulated once per workgroup.
-// Index: flag5 (5 bits) | 32 the reference is known and usable (generic.c:781-801) | 64 a proper-pair insert size
-// (generic.c:838-840) | 128 MAPQ >= -Q. Entry: bit 3k set => cnt[k] += 1 for k in 0..7 (generic.c:1048-1055;
+// Index: flag5 (6 bits) | 64 the reference is known and usable (generic.c:781-801) | 128 a proper-pair insert size
+// (generic.c:838-840) | 256 MAPQ >= -Q. Entry: bit 3k set => cnt[k] += 1 for k in 0..7 (generic.c:1048-1055;
 // cnt[11] == cnt[7] without -R), LUT_OK the record goes on to the lookup, LUT_SE it is measured as a single end.
 #define LUT_OK (1u << 24)
 #define LUT_SE (1u << 25)
 __device__ __forceinline__ uint32_t lut_entry(const ItxRunParams &P, uint32_t idx)
 {
     const bool paired = idx & F5_PAIRED, unmap = idx & F5_UNMAP, munmap = idx & F5_MUNMAP, read1 = idx & F5_READ1;
-    const bool ref_ok = idx & 32u, isz_ok = idx & 64u, uniq = idx & 128u;
+    const bool ref_ok = idx & 64u, isz_ok = idx & 128u, uniq = idx & 256u;
     const bool treat = P.treat != 0;
     const bool end1 = !paired || read1 || treat;                                   // generic.c:748-759
     const bool mapped = !unmap;                                                    // generic.c:764
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t lut_entry(const ItxRunParams &P, uint32_t id
     e |= chrom_ok ? (end1 ? 1u << 12 : 1u << 15) : 0u;
     e |= ok ? 1u << 18 : 0u;
     e |= (ok && uniq) ? 1u << 21 : 0u;
-    return e | (ok ? LUT_OK : 0u) | (se ? LUT_SE : 0u);
+    return e | ((ok && !(idx & F5_NOLOOKUP)) ? LUT_OK : 0u) | (se ? LUT_SE : 0u);      // the caller's -R / XA `continue`
 }
 
 __device__ __forceinline__ uint32_t uadd32(uint32_t a, uint32_t b) { return a + b; }
@@ -84,7 +84,7 @@ __device__ __forceinline__ void derive_one(const ItxRunParams &P, const uint32_t
 {
     const uint32_t cend = ty - 1u;                                                 // generic.c:796
     uq = r.mapq >= P.mapq_min;
-    uint32_t idx = r.fl | (((int32_t)tx >= 0 && cend != 1u) ? 32u : 0u) | (uq ? 128u : 0u);
+    uint32_t idx = r.fl | (((int32_t)tx >= 0 && cend != 1u) ? 64u : 0u) | (uq ? 256u : 0u);
     // generic.c:819-833
     uint32_t s_se = (uint32_t)r.pos;
     uint32_t e_se = umin32(cend, (uint32_t)r.tmpend);
@@ -99,7 +99,7 @@ __device__ __forceinline__ void derive_one(const ItxRunParams &P, const uint32_t
     en = e_se;
     if (tile_pe) {                                                                 // wave-uniform; generic.c:838-855
         const uint32_t aisz = iz < 0 ? 0u - (uint32_t)iz : (uint32_t)iz;
-        idx |= (aisz <= P.isize_max && iz != 0) ? 64u : 0u;
+        idx |= (aisz <= P.isize_max && iz != 0) ? 128u : 0u;
         lut = s_lut[idx];
         const bool se = lut & LUT_SE;
         const bool fwd = iz > 0;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
 {
     // a wave's window: entry 0 is a sentinel no query overlaps and no scan walks past, table row lo_w + i sits at entry i + 1
     __shared__ uint4 s_win[SB / 64][2 * (ITX_WIN + 1)];
-    __shared__ uint32_t s_lut[512];                            // entries 256.. are zero: records past the end carry fl = 256
+    __shared__ uint32_t s_lut[1024];                           // entries 512.. are zero: records past the end carry fl = 512
     __shared__ uint32_t s_cnt[16];
     __shared__ uint32_t s_cursor;
     extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     const uint32_t w = threadIdx.x >> 6;
     uint4 *win = s_win[w];
     s_lut[threadIdx.x] = lut_entry(P, threadIdx.x);
-    s_lut[256 + threadIdx.x] = 0;
+    s_lut[256 + threadIdx.x] = lut_entry(P, 256 + threadIdx.x);
+    s_lut[512 + threadIdx.x] = 0;
+    s_lut[768 + threadIdx.x] = 0;
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_cursor = 0;
     if (lane == 0) {
@@ -200,10 +202,10 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             const int4 e4 = *reinterpret_cast<const int4 *>(B.tmpend + r0);
             const uint32_t mq = *reinterpret_cast<const uint32_t *>(B.mapq + r0);
             const uint32_t f4 = *reinterpret_cast<const uint32_t *>(B.flag5 + r0);
-            raw[0] = {t4.x, p4.x, e4.x, mq & 0xffu, f4 & 0x1fu};
-            raw[1] = {t4.y, p4.y, e4.y, (mq >> 8) & 0xffu, (f4 >> 8) & 0x1fu};
-            raw[2] = {t4.z, p4.z, e4.z, (mq >> 16) & 0xffu, (f4 >> 16) & 0x1fu};
-            raw[3] = {t4.w, p4.w, e4.w, mq >> 24, (f4 >> 24) & 0x1fu};
+            raw[0] = {t4.x, p4.x, e4.x, mq & 0xffu, f4 & 0x3fu};
+            raw[1] = {t4.y, p4.y, e4.y, (mq >> 8) & 0xffu, (f4 >> 8) & 0x3fu};
+            raw[2] = {t4.z, p4.z, e4.z, (mq >> 16) & 0xffu, (f4 >> 16) & 0x3fu};
+            raw[3] = {t4.w, p4.w, e4.w, mq >> 24, (f4 >> 24) & 0x3fu};
 #pragma unroll
             for (int j = 0; j < RPL; j++) ex[j] = true;
             tile_pe = have_pe && __ballot(f4 & 0x01010101u) != 0ull;            // some record of the tile is paired
@@ -217,9 +219,9 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 ex[j] = r0 + j < end;
-                raw[j] = {0, 0, 0, 0, 256u};
+                raw[j] = {0, 0, 0, 0, 512u};
                 if (ex[j]) {
-                    raw[j] = {B.tid[r0 + j], B.pos[r0 + j], B.tmpend[r0 + j], B.mapq[r0 + j], B.flag5[r0 + j] & 0x1fu};
+                    raw[j] = {B.tid[r0 + j], B.pos[r0 + j], B.tmpend[r0 + j], B.mapq[r0 + j], B.flag5[r0 + j] & 0x3fu};
                     if (have_pe) {
                         isz[j] = B.isize[r0 + j];
                         mps[j] = B.mpos[r0 + j];

@@ -14,12 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ITX_LIB", os.path.join(HERE, "libiteres_amd.so"))   # ITX_LIB: timing-only experiment builds
 
 MODE_STAT, MODE_FILTER = 0, 1
+F5_NOLOOKUP = 0x20        # include/iteres_amd.h ITX_F5_NOLOOKUP
 ACCUM_DEFAULT, ACCUM_ATOMIC, ACCUM_PARTITION = 0, 1, 2
 
 EXPORTS = [
     "itx_last_error", "itx_abi_version", "itx_device_count", "itx_table_create", "itx_table_destroy",
     "itx_table_get_info", "itx_table_cov_offsets", "itx_engine_create", "itx_engine_destroy", "itx_engine_set_tidmap",
-    "itx_engine_staging", "itx_engine_submit_slot", "itx_engine_wait_slot", "itx_engine_submit_device",
+    "itx_engine_staging", "itx_engine_submit_slot", "itx_engine_classify_slot", "itx_engine_wait_slot", "itx_engine_submit_device",
     "itx_engine_classify_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
     "itx_engine_partial_size", "itx_engine_export_partial", "itx_engine_finish_partial",
 ]
@@ -94,6 +95,7 @@ def load():
     L.itx_engine_set_tidmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.itx_engine_staging.argtypes = [C.c_void_p, C.c_int, C.POINTER(Staging)]
     L.itx_engine_submit_slot.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int]
+    L.itx_engine_classify_slot.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int]
     L.itx_engine_wait_slot.argtypes = [C.c_void_p, C.c_int]
     L.itx_engine_submit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_void_p, C.c_void_p]
     L.itx_engine_classify_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_void_p, C.c_void_p]
@@ -192,8 +194,9 @@ class Engine:
                 "flag5": view(st.flag5, C.c_uint8, np.uint8), "mpos": view(st.mpos, C.c_int32, np.int32),
                 "isize": view(st.isize, C.c_int32, np.int32), "hit_row": view(st.hit_row, C.c_int32, np.int32)}
 
-    def submit_host(self, tid, pos, tmpend, mapq, flag5_, mpos=None, isize=None, want_hits=False):
-        """Streams host arrays through the pinned double buffers (slot ping-pong). Returns hit rows if asked."""
+    def submit_host(self, tid, pos, tmpend, mapq, flag5_, mpos=None, isize=None, want_hits=False, veto=None):
+        """Streams host arrays through the pinned double buffers (slot ping-pong). Returns hit rows if asked.
+        veto(offset, hit_rows) -> bool mask: records to mark ITX_F5_NOLOOKUP after a classify-only pass."""
         L = load()
         n = len(tid)
         hits = np.empty(n, np.int32) if want_hits else None
@@ -215,6 +218,12 @@ class Engine:
                 bufs[s]["mapq"][:m] = mapq[sl]; bufs[s]["flag5"][:m] = flag5_[sl]
                 if paired:
                     bufs[s]["mpos"][:m] = mpos[sl]; bufs[s]["isize"][:m] = isize[sl]
+                if veto is not None:
+                    # what a caller with an XA-style veto does: classify, look at the chosen rows, mark, then count
+                    _chk(L.itx_engine_classify_slot(self._h, s, m, int(paired)), "itx_engine_classify_slot")
+                    _chk(L.itx_engine_wait_slot(self._h, s), "itx_engine_wait_slot")
+                    mask = np.asarray(veto(off, bufs[s]["hit_row"][:m].copy()), bool)
+                    bufs[s]["flag5"][:m] |= mask.astype(np.uint8) * np.uint8(F5_NOLOOKUP)
                 _chk(L.itx_engine_submit_slot(self._h, s, m, int(paired), int(want_hits)), "itx_engine_submit_slot")
                 pending[s] = (off, off + m)
                 off += m

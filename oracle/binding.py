@@ -43,7 +43,7 @@ def lib():
         L.orc_find.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
         L.orc_cov_offsets.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_run.restype = C.c_int
-        L.orc_run.argtypes = [C.c_void_p, C.POINTER(OrcParams), C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 15
+        L.orc_run.argtypes = [C.c_void_p, C.POINTER(OrcParams), C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 16
         L.orc_hash_string.restype = C.c_uint32
         L.orc_hash_string.argtypes = [C.c_char_p]
         _LIB = L
@@ -82,7 +82,7 @@ class OracleTable:
         n = lib().orc_find(self._h, int(chrom), int(start), int(end), _p(rows), cap)
         return rows[:min(n, cap)].copy()
 
-    def run(self, params: dict, tid2chrom, tid, pos, tmpend, mapq, flag, mpos=None, isize=None, want_hits=True):
+    def run(self, params: dict, tid2chrom, tid, pos, tmpend, mapq, flag, mpos=None, isize=None, want_hits=True, skip=None):
         n = len(tid)
         p = OrcParams(int(params.get("mapq_min", 10)), float(np.float32(params.get("min_cov", 0.0001))),
                       int(params.get("extension", 150)), int(params.get("isize_max", 500)),
@@ -96,6 +96,7 @@ class OracleTable:
         flag = np.ascontiguousarray(flag, np.uint16)
         mpos = np.zeros(n, np.int32) if mpos is None else np.ascontiguousarray(mpos, np.int32)
         isize = np.zeros(n, np.int32) if isize is None else np.ascontiguousarray(isize, np.int32)
+        skip = None if skip is None else np.ascontiguousarray(skip, np.uint8)
         res = {
             "hit_row": np.empty(n, np.int64) if want_hits else None,
             "cnt": np.zeros(13, np.uint64),
@@ -107,7 +108,7 @@ class OracleTable:
             "locus_cnt": np.zeros(max(self.n_rows, 1), np.uint32),
         }
         rc = lib().orc_run(self._h, C.byref(p), len(tid2chrom), _p(tid2chrom), n, _p(tid), _p(pos), _p(tmpend),
-                           _p(mapq), _p(flag), _p(mpos), _p(isize), _p(res["hit_row"]), _p(res["cnt"]),
+                           _p(mapq), _p(flag), _p(mpos), _p(isize), _p(skip), _p(res["hit_row"]), _p(res["cnt"]),
                            _p(res["rep_cnt"]), _p(res["fam_cnt"]), _p(res["cla_cnt"]), _p(res["cov"]),
                            _p(res["cov_uniq"]), _p(res["locus_cnt"]))
         assert rc == 0

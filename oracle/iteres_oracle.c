@@ -223,7 +223,7 @@ static float get_cov(unsigned int aStart, unsigned int aEnd, unsigned int start,
 
 int orc_run(const orc_table *t, const orc_params *p, int n_tid, const int32_t *tid2chrom, size_t n,
             const int32_t *tid, const int32_t *pos, const int32_t *tmpend_a, const uint8_t *mapq,
-            const uint16_t *flag, const int32_t *mpos, const int32_t *isize, int64_t *hit_row,
+            const uint16_t *flag, const int32_t *mpos, const int32_t *isize, const uint8_t *skip, int64_t *hit_row,
             uint64_t *cnt, uint64_t *rep_cnt, uint64_t *fam_cnt, uint64_t *cla_cnt, uint32_t *cov,
             uint32_t *cov_uniq, uint32_t *locus_cnt)
 {
@@ -315,6 +315,8 @@ int orc_run(const orc_table *t, const orc_params *p, int n_tid, const int32_t *t
         /* generic.c:921-922 */
         if (qual >= mapQ)
             cnt[11]++;
+        if (skip && skip[r])
+            continue;
 
         /* generic.c:939-970 */
         unsigned int qlen = end - start;

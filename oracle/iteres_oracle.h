@@ -65,10 +65,14 @@ void orc_cov_offsets(const orc_table *t, uint64_t *off);
  * the chrom-size file (generic.c:793-801), -2 when -C drops it ("GL*", generic.c:783-784).
  * Outputs (all accumulated into, caller zeroes): hit_row[i] = chosen rmsk row or -1;
  * cnt[13] (generic.c:1048-1060); rep/fam/cla counters [0..n) all reads, [n..2n) unique reads;
- * cov / cov_uniq per orc_cov_offsets; locus_cnt[row] (filter mode, slCount of ss->sl). */
+ * cov / cov_uniq per orc_cov_offsets; locus_cnt[row] (filter mode, slCount of ss->sl).
+ * skip (may be NULL): skip[r] != 0 marks a record the reference would leave with one of the two `continue`s
+ * between the mapped-read counters and the accumulation — a -R duplicate (generic.c:907-919) or an XA veto
+ * (generic.c:972-982), both decided by string logic outside this restatement; such a record is counted up to
+ * cnt[11] and goes no further. */
 int orc_run(const orc_table *t, const orc_params *p, int n_tid, const int32_t *tid2chrom, size_t n,
             const int32_t *tid, const int32_t *pos, const int32_t *tmpend, const uint8_t *mapq,
-            const uint16_t *flag, const int32_t *mpos, const int32_t *isize, int64_t *hit_row,
+            const uint16_t *flag, const int32_t *mpos, const int32_t *isize, const uint8_t *skip, int64_t *hit_row,
             uint64_t *cnt, uint64_t *rep_cnt, uint64_t *fam_cnt, uint64_t *cla_cnt, uint32_t *cov,
             uint32_t *cov_uniq, uint32_t *locus_cnt);
 

@@ -25,10 +25,18 @@ def oracle_table(rows, chrom_size, rep_len, n_fam, n_cla):
 
 
 def run_both(rows, chrom_size, rep_len, n_fam, n_cla, params, tid2chrom, rd, batch_capacity=1 << 16, accum=eng.ACCUM_DEFAULT,
-             via="host"):
-    """rd: dict tid,pos,tmpend,mapq,flag(16-bit BAM flags),mpos,isize. Returns (engine_result, oracle_result, hits_e)."""
+             via="host", skip=None, veto=None):
+    """rd: dict tid,pos,tmpend,mapq,flag(16-bit BAM flags),mpos,isize. Returns (engine_result, oracle_result, hits_e).
+    skip: bool mask of records the caller marks ITX_F5_NOLOOKUP up front (a -R duplicate); veto(hit_rows) -> bool mask:
+    records marked after a classify-only pass (an XA veto). The oracle gets the union as its `skip`."""
     ot = oracle_table(rows, chrom_size, rep_len, n_fam, n_cla)
-    ores = ot.run(params, tid2chrom, rd["tid"], rd["pos"], rd["tmpend"], rd["mapq"], rd["flag"], rd.get("mpos"), rd.get("isize"))
+    args = (params, tid2chrom, rd["tid"], rd["pos"], rd["tmpend"], rd["mapq"], rd["flag"], rd.get("mpos"), rd.get("isize"))
+    oskip = None if skip is None else np.asarray(skip, bool).copy()
+    if veto is not None:
+        first = ot.run(*args, skip=oskip)
+        v = np.asarray(veto(first["hit_row"]), bool)
+        oskip = v if oskip is None else (oskip | v)
+    ores = ot.run(*args, skip=oskip)
     ot.close()
     t = eng.Table(rows, chrom_size, rep_len, n_fam, n_cla)
     p = dict(params)
@@ -36,9 +44,12 @@ def run_both(rows, chrom_size, rep_len, n_fam, n_cla, params, tid2chrom, rd, bat
     e = eng.Engine(t, p, batch_capacity=batch_capacity)
     e.set_tidmap(tid2chrom)
     f5 = eng.flag5(rd["flag"])
+    if skip is not None:
+        f5 = f5 | (np.asarray(skip, bool).astype(np.uint8) * np.uint8(eng.F5_NOLOOKUP))
     paired = bool((np.asarray(rd["flag"]) & 1).any())
     hits = e.submit_host(rd["tid"], rd["pos"], rd["tmpend"], rd["mapq"], f5, rd["mpos"] if paired else None,
-                         rd["isize"] if paired else None, want_hits=True)
+                         rd["isize"] if paired else None, want_hits=True,
+                         veto=None if veto is None else (lambda off, h: veto(h.astype(np.int64))))
     eres = e.finish()
     e.close()
     t.close()

@@ -133,6 +133,40 @@ def test_f32_ratio_exactness():
     assert 0.02 < (ores["hit_row"] >= 0).mean() < 0.5       # the last threshold really cuts
 
 
+def test_min_cov_band():
+    """Quotients within 2^-20 of -c leave the one-multiply test (itx_cov_bounds) for the exact division: overlaps of
+    qlen/2 + d against -c 0.5 with qlen = 2^22 sit 2^-22 apart around the threshold."""
+    size = 100_000_000
+    qlen = 1 << 22
+    R = 50_000_000
+    rows = eng.make_rows([0], [R], [R + 20_000_000], [0], [500], [0], [0], [0])
+    rl = np.array([500], np.uint32)
+    d = np.arange(-40, 41)
+    pos = (R - (qlen // 2 - d)).astype(np.int32)
+    m = len(pos)
+    rd = {"tid": np.zeros(m, np.int32), "pos": pos, "tmpend": (pos + qlen).astype(np.int32), "mapq": np.full(m, 40, np.uint8),
+          "flag": np.zeros(m, np.uint16), "mpos": np.zeros(m, np.int32), "isize": np.zeros(m, np.int32)}
+    for mc in (0.5, 0.5000001, 0.4999999, 0.50000006):
+        eres, ores, hits = ec.run_both(rows, [size], rl, 1, 1, dict(extension=0, min_cov=mc), [0], rd)
+        ec.assert_same(eres, ores, hits, False, 1)
+        assert 0 < (ores["hit_row"] >= 0).sum() < m          # the threshold falls inside the sweep
+
+
+@pytest.mark.parametrize("accum", ACCUMS)
+def test_nolookup_and_veto(accum):
+    """ITX_F5_NOLOOKUP: records a caller takes out between the mapped-read counters and the lookup (-R duplicates,
+    marked up front; XA vetoes, marked after a classify-only pass over the slot) — counted, never accumulated."""
+    chroms = [("c1", 40_000_000), ("c2", 9_000_000)]
+    rows, cs, rl, nf, nc, t2c, rd = _synth_case(77, 60_000, 300_000, chroms, paired=0.3)
+    rng = np.random.default_rng(79)
+    skip = rng.random(len(rd["tid"])) < 0.2
+    veto = lambda h: (h >= 0) & (h % 3 == 0)
+    for kw in (dict(skip=skip), dict(veto=veto), dict(skip=skip, veto=veto)):
+        eres, ores, hits = ec.run_both(rows, cs, rl, nf, nc, dict(), t2c, rd, batch_capacity=50_001, accum=accum, **kw)
+        ec.assert_same(eres, ores, hits, False, len(rows))
+    assert (ores["hit_row"] >= 0).sum() > 10_000
+
+
 def test_properties_at_scale():
     """2 M reads vs 300 k rows: results must not depend on how the stream is cut into batches, on record order,
     or on the accumulate path (all sums are integer and commutative)."""

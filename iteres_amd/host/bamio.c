@@ -165,6 +165,15 @@ static size_t bgzf_read(aln_reader *r, void *dst, size_t n)
     return k;
 }
 
+static char *xstrndup_bound(const char *s, size_t max)
+{
+    const size_t k = strnlen(s, max);
+    char *d = xmalloc(k + 1);
+    memcpy(d, s, k);
+    d[k] = 0;
+    return d;
+}
+
 static int32_t rd_i32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
 static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 
@@ -275,14 +284,14 @@ void aln_close(aln_reader *r)
 int aln_n_targets(const aln_reader *r) { return r->n_targets; }
 const char *aln_target_name(const aln_reader *r, int tid) { return r->tname[tid]; }
 
-/* bam_aux.c:36-48: does the aux block hold tag `t0 t1`? */
-static int aux_has_tag(const uint8_t *s, const uint8_t *end, char t0, char t1)
+/* bam_aux.c:36-48 (the aux walk of bam_aux_get): pointer to the type byte of the first tag `t0 t1`, or NULL */
+static const uint8_t *aux_find(const uint8_t *s, const uint8_t *end, char t0, char t1)
 {
     while (s + 3 <= end) {
         const int hit = s[0] == (uint8_t)t0 && s[1] == (uint8_t)t1;
         const int type = toupper(s[2]);
+        if (hit) return s + 2;
         s += 3;
-        if (hit) return 1;
         if (type == 'A' || type == 'C') s += 1;
         else if (type == 'S') s += 2;
         else if (type == 'I' || type == 'F') s += 4;
@@ -291,19 +300,32 @@ static int aux_has_tag(const uint8_t *s, const uint8_t *end, char t0, char t1)
             while (s < end && *s) ++s;
             ++s;
         } else if (type == 'B') {
-            if (s + 5 > end) return 0;
+            if (s + 5 > end) return NULL;
             const int sub = toupper(s[0]);
             const uint32_t cnt = rd_u32(s + 1);
             const size_t esz = (sub == 'C' || sub == 'A') ? 1 : (sub == 'S') ? 2 : 4;
             s += 5 + (size_t)cnt * esz;
         } else
-            return 0;
+            return NULL;
     }
+    return NULL;
+}
+
+/* bam_aux2i, bam_aux.c:159-170 */
+static int32_t aux_to_int(const uint8_t *s, const uint8_t *end)
+{
+    if (!s) return 0;
+    const int type = *s++;
+    if (type == 'c' && s + 1 <= end) return (int32_t)(int8_t)s[0];
+    if (type == 'C' && s + 1 <= end) return (int32_t)s[0];
+    if (type == 's' && s + 2 <= end) return (int32_t)(int16_t)(s[0] | s[1] << 8);
+    if (type == 'S' && s + 2 <= end) return (int32_t)(uint16_t)(s[0] | s[1] << 8);
+    if ((type == 'i' || type == 'I') && s + 4 <= end) return rd_i32(s);
     return 0;
 }
 
 /* bam.c:179-210 for one record that is completely in memory */
-static inline void bam_parse_one(const uint8_t *p, size_t n, itx_staging *st, char **qnames, int *any_paired, int *aux_xa)
+static inline void bam_parse_one(const uint8_t *p, size_t n, itx_staging *st, aln_side *side, int *any_paired, int *aux_xa)
 {
     const int32_t block_len = rd_i32(p);
     const uint8_t *core = p + 4, *data = p + 36;
@@ -332,13 +354,26 @@ static inline void bam_parse_one(const uint8_t *p, size_t n, itx_staging *st, ch
     st->mpos[n] = mpos;
     st->isize[n] = isize;
     if (flag & 1) *any_paired = 1;
-    if (qnames) qnames[n] = xstrdup(l_qname && l_qname <= dlen ? (const char *)data : "");
+    if (side && side->want_qnames) side->qname[n] = xstrdup(l_qname && l_qname <= dlen ? (const char *)data : "");
     const size_t ql = l_qseq > 0 ? (size_t)l_qseq : 0;
     const size_t off = (size_t)l_qname + 4 * (size_t)n_cigar + (ql + 1) / 2 + ql;
-    if (off < dlen && aux_has_tag(data + off, data + dlen, 'X', 'A')) *aux_xa = 1;
+    const uint8_t *xa = off < dlen ? aux_find(data + off, data + dlen, 'X', 'A') : NULL;
+    if (xa) *aux_xa = 1;
+    if (side && side->want_aux) {
+        side->xa[n] = NULL;
+        side->nm[n] = 0;
+        if (xa) {
+            /* bam_aux2Z (bam_aux.c:193-199): the string of a Z/H tag; an XA tag of another type has no string the
+             * reference could copy (it would crash there) and reads as empty here */
+            const uint8_t *e = data + dlen;
+            const char *z = (*xa == 'Z' || *xa == 'H') ? (const char *)(xa + 1) : "";
+            side->xa[n] = xstrndup_bound(z, (*xa == 'Z' || *xa == 'H') ? (size_t)(e - (xa + 1)) : 0);
+            side->nm[n] = aux_to_int(aux_find(data + off, e, 'N', 'M'), e);
+        }
+    }
 }
 
-static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa)
+static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
     size_t n = 0;
     while (n < cap) {
@@ -377,7 +412,7 @@ static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **
 #pragma omp parallel for schedule(static) reduction(| : ap, xa)
         for (long i = 0; i < (long)m; i++) {
             int a1 = 0, x1 = 0;
-            bam_parse_one(r->ubuf + ro[i], n + (size_t)i, st, qnames, &a1, &x1);
+            bam_parse_one(r->ubuf + ro[i], n + (size_t)i, st, side, &a1, &x1);
             ap |= a1;
             xa |= x1;
         }
@@ -412,7 +447,7 @@ static unsigned flag_from_chars(const char *s)
     return f;
 }
 
-static size_t sam_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa)
+static size_t sam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
     size_t n = 0;
     while (n < cap) {
@@ -484,20 +519,32 @@ static size_t sam_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **
         st->mpos[n] = mpos;
         st->isize[n] = isize;
         if (flag & 1) *any_paired = 1;
-        if (qnames) qnames[n] = xstrdup(fld[0]);
-        if (!*aux_xa && nf == 12) {
-            for (char *a = fld[11]; a; a = strchr(a, '\t') ? strchr(a, '\t') + 1 : NULL)
-                if (strncmp(a, "XA:", 3) == 0) {
-                    *aux_xa = 1;
-                    break;
-                }
+        if (side && side->want_qnames) side->qname[n] = xstrdup(fld[0]);
+        if (side && side->want_aux) {
+            side->xa[n] = NULL;
+            side->nm[n] = 0;
+        }
+        if (nf == 12) {
+            /* optional fields TAG:TYPE:VALUE (bam_import.c:402-470); the first XA and the first NM count (bam_aux_get) */
+            const char *xa = NULL, *nm = NULL;
+            for (char *a = fld[11]; a; a = strchr(a, '\t') ? strchr(a, '\t') + 1 : NULL) {
+                if (!xa && strncmp(a, "XA:", 3) == 0) xa = a;
+                if (!nm && strncmp(a, "NM:", 3) == 0) nm = a;
+            }
+            if (xa) *aux_xa = 1;
+            if (xa && side && side->want_aux) {
+                const int is_z = strlen(xa) >= 5 && (xa[3] == 'Z' || xa[3] == 'H') && xa[4] == ':';
+                const char *v = is_z ? xa + 5 : "";
+                side->xa[n] = xstrndup_bound(v, strcspn(v, "\t"));
+                if (nm && strlen(nm) >= 5 && nm[3] == 'i' && nm[4] == ':') side->nm[n] = (int32_t)strtol(nm + 5, NULL, 10);
+            }
         }
         n++;
     }
     return n;
 }
 
-size_t aln_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa)
+size_t aln_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
-    return r->is_sam ? sam_read_batch(r, st, cap, qnames, any_paired, aux_xa) : bam_read_batch(r, st, cap, qnames, any_paired, aux_xa);
+    return r->is_sam ? sam_read_batch(r, st, cap, side, any_paired, aux_xa) : bam_read_batch(r, st, cap, side, any_paired, aux_xa);
 }

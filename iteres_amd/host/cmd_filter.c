@@ -99,7 +99,6 @@ int main_filter(int argc, char **argv)
         output = filename_without_ext(basename(copy));
         free(copy);
     }
-    if (o.dedup) die("-R (remove redundant reads, generic.c:907-919) is not built into this version");
 
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
@@ -117,7 +116,8 @@ int main_filter(int argc, char **argv)
     itx_engine *eng = NULL;
     itx_table *tab = NULL;
     char **locus_names = NULL;
-    run_stream(&o, &rm, &chr_sizes, 1, 0, 10000, optreadlist, &eng, &tab, optreadlist ? &locus_names : NULL);
+    host_counts hc = {0, 0};
+    run_stream(&o, &rm, &chr_sizes, 1, 0, 10000, optreadlist, &eng, &tab, optreadlist ? &locus_names : NULL, &hc);
 
     fprintf(stderr, "* Preparing the output file\n");
     char *out = NULL, *outReport = NULL;
@@ -129,6 +129,7 @@ int main_filter(int argc, char **argv)
     res.cnt = cnt;
     res.locus_cnt = xcalloc(rm.n_rows + 1, sizeof(uint32_t));
     if (itx_engine_finish(eng, &res) != ITX_OK) die("itx_engine_finish: %s", itx_last_error());
+    cnt[11] -= hc.dup_unique;                     /* reads_nonredundant_unique: -R duplicates never reach it (generic.c:524-539) */
     write_filter_out(&rm, res.locus_cnt, locus_names, out, optreadlist, optthreshold, subfam, cnt[nindex]);
     fprintf(stderr, "* Preparing report file\n");
     write_report(outReport, cnt, o.mapq, subfam);

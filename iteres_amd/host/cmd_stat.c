@@ -123,9 +123,8 @@ int main_stat(int argc, char **argv)
     else if (optNorm2 == 1) nindex2 = 7;
     else if (optNorm2 == 2) nindex2 = 0;
     else die("Wrong normalization method specified");
-    /* features of the reference that stay on the host and are not built yet: fail loudly rather than differ */
-    if (o.dedup) die("-R (remove redundant reads, generic.c:907-919) is not built into this version");
-    if (optBed || optBedUniq) die("-B / -V (bed output, generic.c:925-936) is not built into this version");
+    if (optBed) o.bed_path = fmt_name(output, ".iteres.bed");                     /* stat.c:104-111 */
+    if (optBedUniq) o.bed_uniq_path = fmt_name(output, ".iteres.unique.bed");
 
     const int timing = getenv("ITX_TIMING") != NULL;
     const double t_begin = now_s();
@@ -141,7 +140,8 @@ int main_stat(int argc, char **argv)
     fprintf(stderr, "* Parsing the SAM/BAM file\n");
     itx_engine *eng = NULL;
     itx_table *tab = NULL;
-    run_stream(&o, &rm, &chr_sizes, 0, 1, 100000, 0, &eng, &tab, NULL);
+    host_counts hc = {0, 0};
+    run_stream(&o, &rm, &chr_sizes, 0, 1, 100000, 0, &eng, &tab, NULL, &hc);
 
     const double t_streamed = now_s();
     fprintf(stderr, "* Writing stats and Wig file\n");
@@ -157,6 +157,8 @@ int main_stat(int argc, char **argv)
     res.cov = xcalloc(info.cov_len + 1, sizeof(uint32_t));
     res.cov_uniq = xcalloc(info.cov_len + 1, sizeof(uint32_t));
     if (itx_engine_finish(eng, &res) != ITX_OK) die("itx_engine_finish: %s", itx_last_error());
+    cnt[11] -= hc.dup_unique;                     /* reads_nonredundant_unique: -R duplicates never reach it (generic.c:907-922) */
+    cnt[12] = hc.diff_subfam;                     /* reads_diff_subfam (generic.c:978) */
     uint64_t *cov_off = xcalloc((size_t)rm.reps.n + 1, sizeof(uint64_t));
     itx_table_cov_offsets(tab, cov_off);
     write_wig_and_stat(&rm, &res, cov_off, outStat, o.keep_wig ? outWig : NULL, outFam, outCla, o.keep_wig ? outWigUniq : NULL, cnt[nindex],

@@ -72,10 +72,16 @@ aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the fi
 void aln_close(aln_reader *r);
 int aln_n_targets(const aln_reader *r);
 const char *aln_target_name(const aln_reader *r, int tid);
+/* What the decoder keeps per record beside the SoA, when the caller wants it (arrays of the batch capacity). */
+typedef struct {
+    int want_qnames, want_aux;
+    char **qname;              /* malloc'd copies of the read names (filter -r, stat -B/-V)                              */
+    char **xa;                 /* malloc'd value of the XA:Z tag, NULL when the record has none (bam_aux2Z, bam_aux.c:193) */
+    int32_t *nm;               /* NM:i, 0 when absent (bam_aux2i, bam_aux.c:159-170)                                      */
+} aln_side;
 /* Fills up to cap records of the staging slot; returns the number read (0 at end of input).
- * qnames: when non-NULL, receives malloc'd copies of the read names (filter -r).
- * *any_paired is set when a record with the PAIRED flag was seen; *aux_xa when a record carries an XA tag. */
-size_t aln_read_batch(aln_reader *r, itx_staging *st, size_t cap, char **qnames, int *any_paired, int *aux_xa);
+ * side may be NULL. *any_paired is set when a record with the PAIRED flag was seen; *aux_xa when one carries an XA tag. */
+size_t aln_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa);
 
 /* ---- shared by the two drivers */
 typedef struct {
@@ -83,14 +89,39 @@ typedef struct {
     unsigned mapq, isize, extension;
     float min_cov;
     const char *chr_size_file, *rep_size_file, *rmsk_file, *aln_arg;
+    const char *bed_path, *bed_uniq_path;      /* stat -B / -V (generic.c:925-936), NULL = off */
 } run_opts;
+/* counters of the record loop that only the host sees (generic.c:1048-1060) */
+typedef struct {
+    unsigned long long diff_subfam;            /* cnt[12]: records the XA veto dropped                                  */
+    unsigned long long dup_unique;             /* MAPQ >= -Q records -R dropped: cnt[11] = cnt[7] - dup_unique         */
+} host_counts;
+
+/* ---- side.c: the string / file-order parts of the record loop */
+typedef struct {
+    uint32_t start, end;
+    char strand;
+} host_iv;
+/* generic.c:764-905: 1 when the record reaches reads_mapped++ (then *d is its interval), chrom as in the tid map */
+int host_derive(const run_opts *o, int32_t chrom, int64_t chrom_size, unsigned flag5, int32_t pos, int32_t tmpend, int32_t mpos, int32_t isize,
+                host_iv *d);
+typedef struct dup_set dup_set;
+dup_set *dup_set_new(void);
+void dup_set_free(dup_set *s);
+int dup_set_seen(dup_set *s, uint32_t chr_name_id, const host_iv *d, int uniq);      /* generic.c:907-919: 1 = drop */
+typedef struct xa_index xa_index;
+xa_index *xa_index_new(const rmsk_t *rm);
+void xa_index_free(xa_index *x);
+/* generic.c:303-341: 1 = veto. chosen_rep: repName id of the chosen row; xa is chopped in place. */
+int xa_veto(const xa_index *x, uint32_t chosen_rep, int nm, char *xa, int qlen);
 /* generic.c:7-15 */
 char *filename_without_ext(const char *path);
 /* Runs the record loop (generic.c:700-1062 / 343-697) over one or more files through the engine.
  * progress_every: 100000 (stat, generic.c:760) or 10000 (filter, generic.c:397). want_qnames: per-locus read
  * names (filter -r): *locus_names[row] receives a comma-joined list in BAM order. */
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
-                unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names);
+                unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names,
+                host_counts *hc);
 
 /* writers (generic.c:35-41,53-113,1709-1746) */
 double cal_rpkm(unsigned long long reads, unsigned long long total_length, unsigned long long mapped);

@@ -1,10 +1,12 @@
 /* stream.c — the record loop of the reference (generic.c:700-1062 stat copy, 343-697 filter copy) as a host
  * pipeline around the GPU engine: decode a batch into one pinned staging slot while the other slot is in
  * flight (itx_engine_staging / submit_slot / wait_slot), keep what is order-dependent or text on the host
- * (progress banners, the "chromosome not in the size file" warnings, read names for filter -r). */
+ * (progress banners, the "chromosome not in the size file" warnings, read names for filter -r, and — side.c —
+ * the -R duplicate filter, the -B/-V bed lines and the XA veto, which reach the engine as one flag bit per record). */
 #define _GNU_SOURCE
 #include "itx_host.h"
 
+#include <errno.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
@@ -35,8 +37,48 @@ typedef struct {
     char *name;
 } hit_name;
 
+typedef struct {
+    hit_name *v;
+    size_t n, cap;
+} hit_names;
+
+/* filter -r: keep the names of the records that chose a row, free the others */
+static void collect_names(hit_names *hn, const itx_staging *st, aln_side *side, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        const int32_t row = st->hit_row[i];
+        if (row >= 0) {
+            if (hn->n == hn->cap) {
+                hn->cap = hn->cap ? hn->cap * 2 : 1 << 16;
+                hn->v = xrealloc(hn->v, sizeof *hn->v * hn->cap);
+            }
+            hn->v[hn->n].row = (uint32_t)row;
+            hn->v[hn->n].name = side->qname[i];
+            hn->n++;
+        } else {
+            free(side->qname[i]);
+        }
+        side->qname[i] = NULL;
+    }
+}
+
+static void side_release(aln_side *side, size_t n, int keep_qnames)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (side->want_qnames && !keep_qnames) {
+            free(side->qname[i]);
+            side->qname[i] = NULL;
+        }
+        if (side->want_aux) {
+            free(side->xa[i]);
+            side->xa[i] = NULL;
+        }
+    }
+}
+
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
-                unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names)
+                unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names,
+                host_counts *hc)
 {
     const int timing = getenv("ITX_TIMING") != NULL;
     struct timespec ts0, ts1;
@@ -72,14 +114,38 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     chk(itx_engine_staging(eng, 0, &st[0]), "itx_engine_staging");
     chk(itx_engine_staging(eng, 1, &st[1]), "itx_engine_staging");
 
-    char **qn[2] = {NULL, NULL};
+    /* what the host keeps per record beside the SoA */
+    const int want_bed = o->bed_path || o->bed_uniq_path;
+    const int veto_on = o->xa_veto && !filter_mode;                    /* filter.c:134 passes diffSubfam = 0 */
+    aln_side side[2];
     size_t pend[2] = {0, 0};
-    hit_name *hn = NULL;
-    size_t n_hn = 0, cap_hn = 0;
-    if (want_qnames) {
-        qn[0] = xcalloc(BATCH_RECORDS, sizeof(char *));
-        qn[1] = xcalloc(BATCH_RECORDS, sizeof(char *));
+    for (int k = 0; k < 2; k++) {
+        memset(&side[k], 0, sizeof side[k]);
+        side[k].want_qnames = want_qnames || want_bed;
+        side[k].want_aux = veto_on || o->bed_path != NULL;
+        if (side[k].want_qnames) side[k].qname = xcalloc(BATCH_RECORDS, sizeof(char *));
+        if (side[k].want_aux) {
+            side[k].xa = xcalloc(BATCH_RECORDS, sizeof(char *));
+            side[k].nm = xcalloc(BATCH_RECORDS, sizeof(int32_t));
+        }
     }
+    const int any_side = side[0].want_qnames || side[0].want_aux;
+    hit_names hn = {NULL, 0, 0};
+    host_iv *iv = NULL;
+    uint8_t *live = NULL;                                              /* the record reached the bed / veto stage */
+    if (o->dedup || want_bed || veto_on) {
+        iv = xcalloc(BATCH_RECORDS, sizeof *iv);
+        live = xcalloc(BATCH_RECORDS, 1);
+    }
+    dup_set *dups = o->dedup ? dup_set_new() : NULL;                   /* one set over all files, like `dup` (generic.c:721) */
+    names_t chr_names;                                                 /* identities of the chromosome strings inside -R keys */
+    names_init(&chr_names);
+    xa_index *xi = NULL;
+    FILE *bed_f = NULL, *bed_uniq_f = NULL;
+    /* mustOpen, cuskent/common.c:2543-2568 */
+    if (o->bed_path && !(bed_f = fopen(o->bed_path, "w"))) die("mustOpen: Can't open %s to write: %s", o->bed_path, strerror(errno));
+    if (o->bed_uniq_path && !(bed_uniq_f = fopen(o->bed_uniq_path, "w")))
+        die("mustOpen: Can't open %s to write: %s", o->bed_uniq_path, strerror(errno));
     unsigned long long ends = 0;
 
     /* the list of files (stat: comma separated, generic.c:725; filter: one file) */
@@ -108,6 +174,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         }
         const int nt = aln_n_targets(rd);
         int32_t *t2c = xmalloc(sizeof(int32_t) * (size_t)(nt + 1));
+        uint32_t *t2id = xcalloc((size_t)nt + 1, sizeof(uint32_t));
         char **t2name = xcalloc((size_t)nt + 1, sizeof(char *));
         for (int t = 0; t < nt; t++) {
             char buf[4096];
@@ -119,6 +186,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                 const int64_t id = names_find(&chr_sizes->names, nm);
                 /* generic.c:796-797: cend = size-1 with 2 as the "not found" default; a listed size of 2 reads the same */
                 t2c[t] = (id >= 0 && (int)chr_sizes->value[id] != 2) ? (int32_t)id : -1;
+                if (dups) t2id[t] = names_intern(&chr_names, nm);
             }
         }
         chk(itx_engine_set_tidmap(eng, t2c, nt > 0 ? nt : 0), "itx_engine_set_tidmap");
@@ -131,29 +199,13 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         for (;;) {
             /* slot s: collect what its previous batch left behind, then refill */
             chk(itx_engine_wait_slot(eng, s), "itx_engine_wait_slot");
-            if (want_qnames && pend[s]) {
-                for (size_t i = 0; i < pend[s]; i++) {
-                    const int32_t row = st[s].hit_row[i];
-                    if (row >= 0) {
-                        if (n_hn == cap_hn) {
-                            cap_hn = cap_hn ? cap_hn * 2 : 1 << 16;
-                            hn = xrealloc(hn, sizeof *hn * cap_hn);
-                        }
-                        hn[n_hn].row = (uint32_t)row;
-                        hn[n_hn].name = qn[s][i];
-                        n_hn++;
-                    } else {
-                        free(qn[s][i]);
-                    }
-                    qn[s][i] = NULL;
-                }
+            if (pend[s]) {
+                if (want_qnames) collect_names(&hn, &st[s], &side[s], pend[s]);
+                side_release(&side[s], pend[s], want_qnames);
                 pend[s] = 0;
             }
-            const size_t n = aln_read_batch(rd, &st[s], BATCH_RECORDS, want_qnames ? qn[s] : NULL, &any_paired, &aux_xa);
+            const size_t n = aln_read_batch(rd, &st[s], BATCH_RECORDS, any_side ? &side[s] : NULL, &any_paired, &aux_xa);
             if (n == 0) break;
-            if (aux_xa && o->xa_veto)
-                die("this alignment file carries XA tags: the XA/NM multi-mapping veto (generic.c:972-982) is not built into this "
-                    "version — rerun with -x to count such reads as the reference does with -x");
             for (size_t i = 0; i < n; i++) {
                 /* generic.c:760-761 progress; generic.c:793-801 one warning per unknown chromosome */
                 if (++ends % progress_every == 0) fprintf(stderr, "\r* Processed read ends: %llu", ends);
@@ -164,6 +216,49 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                           t2name[t], t2name[t]);
                 }
             }
+            /* ---- in file order: -R and the bed lines (generic.c:907-936) */
+            int batch_xa = 0;
+            if (live) {
+                for (size_t i = 0; i < n; i++) {
+                    const int32_t t = st[s].tid[i];
+                    const int32_t chrom = (t >= 0 && t < nt) ? t2c[t] : -1;
+                    live[i] = 0;
+                    if (!host_derive(o, chrom, chrom >= 0 ? chr_sizes->value[chrom] : 0, st[s].flag5[i], st[s].pos[i], st[s].tmpend[i],
+                                     st[s].mpos[i], st[s].isize[i], &iv[i]))
+                        continue;
+                    const int uniq = st[s].mapq[i] >= o->mapq;
+                    if (dups && dup_set_seen(dups, t2id[t], &iv[i], uniq)) {
+                        st[s].flag5[i] |= ITX_F5_NOLOOKUP;
+                        if (uniq && hc) hc->dup_unique++;
+                        continue;
+                    }
+                    live[i] = 1;
+                    const char *xa = side[s].want_aux ? side[s].xa[i] : NULL;
+                    if (xa) batch_xa = 1;
+                    if (bed_f) {
+                        fprintf(bed_f, "%s\t%u\t%u\t%s\t%i\t%c", t2name[t], iv[i].start, iv[i].end, side[s].qname[i], (int)st[s].mapq[i], iv[i].strand);
+                        if (xa) fprintf(bed_f, "\t%i\t%s", (int)side[s].nm[i], xa);
+                        fprintf(bed_f, "\n");
+                    }
+                    if (bed_uniq_f && uniq)
+                        fprintf(bed_uniq_f, "%s\t%u\t%u\t%s\t%i\t%c\n", t2name[t], iv[i].start, iv[i].end, side[s].qname[i], (int)st[s].mapq[i],
+                                iv[i].strand);
+                }
+            }
+            /* ---- the XA veto needs the chosen row first: classify the slot, look, mark, then count (generic.c:972-982) */
+            if (veto_on && batch_xa) {
+                if (!xi) xi = xa_index_new(rm);
+                chk(itx_engine_classify_slot(eng, s, n, any_paired), "itx_engine_classify_slot");
+                chk(itx_engine_wait_slot(eng, s), "itx_engine_wait_slot");
+                for (size_t i = 0; i < n; i++) {
+                    if (!live[i] || !side[s].xa[i] || st[s].hit_row[i] < 0) continue;
+                    const uint32_t rep = rm->rows[st[s].hit_row[i]].rep;
+                    if (xa_veto(xi, rep, side[s].nm[i], side[s].xa[i], (int)(iv[i].end - iv[i].start))) {
+                        st[s].flag5[i] |= ITX_F5_NOLOOKUP;
+                        if (hc) hc->diff_subfam++;
+                    }
+                }
+            }
             chk(itx_engine_submit_slot(eng, s, n, any_paired, want_qnames), "itx_engine_submit_slot");
             pend[s] = n;
             s ^= 1;
@@ -171,59 +266,57 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         /* drain both slots before the tid map of the next file replaces this one */
         for (int k = 0; k < 2; k++) {
             chk(itx_engine_wait_slot(eng, k), "itx_engine_wait_slot");
-            if (want_qnames && pend[k]) {
-                for (size_t i = 0; i < pend[k]; i++) {
-                    const int32_t row = st[k].hit_row[i];
-                    if (row >= 0) {
-                        if (n_hn == cap_hn) {
-                            cap_hn = cap_hn ? cap_hn * 2 : 1 << 16;
-                            hn = xrealloc(hn, sizeof *hn * cap_hn);
-                        }
-                        hn[n_hn].row = (uint32_t)row;
-                        hn[n_hn].name = qn[k][i];
-                        n_hn++;
-                    } else {
-                        free(qn[k][i]);
-                    }
-                    qn[k][i] = NULL;
-                }
+            if (pend[k]) {
+                if (want_qnames) collect_names(&hn, &st[k], &side[k], pend[k]);
+                side_release(&side[k], pend[k], want_qnames);
             }
             pend[k] = 0;
         }
         fprintf(stderr, "\r* Processed read ends: %llu\n", ends);
         for (int t = 0; t < nt; t++) free(t2name[t]);
         free(t2name);
+        free(t2id);
         free(t2c);
         aln_close(rd);
     }
     names_free(&warned);
+    names_free(&chr_names);
     free(arg);
+    if (bed_f) fclose(bed_f);
+    if (bed_uniq_f) fclose(bed_uniq_f);
+    dup_set_free(dups);
+    xa_index_free(xi);
+    free(iv);
+    free(live);
 
     if (want_qnames && locus_names) {
         /* names per locus in BAM order (generic.c:1729 reverses the head-inserted list back to file order) */
         char **out = xcalloc(rm->n_rows ? rm->n_rows : 1, sizeof(char *));
         size_t *len = xcalloc(rm->n_rows ? rm->n_rows : 1, sizeof(size_t));
-        for (size_t i = 0; i < n_hn; i++) len[hn[i].row] += strlen(hn[i].name) + 1;
+        for (size_t i = 0; i < hn.n; i++) len[hn.v[i].row] += strlen(hn.v[i].name) + 1;
         for (size_t r = 0; r < rm->n_rows; r++)
             if (len[r]) {
                 out[r] = xmalloc(len[r] + 1);
                 out[r][0] = 0;
                 len[r] = 0;
             }
-        for (size_t i = 0; i < n_hn; i++) {
-            char *dst = out[hn[i].row] + len[hn[i].row];
-            const size_t k = strlen(hn[i].name);
-            if (len[hn[i].row]) *dst++ = ',', len[hn[i].row]++;
-            memcpy(dst, hn[i].name, k + 1);
-            len[hn[i].row] += k;
-            free(hn[i].name);
+        for (size_t i = 0; i < hn.n; i++) {
+            char *dst = out[hn.v[i].row] + len[hn.v[i].row];
+            const size_t k = strlen(hn.v[i].name);
+            if (len[hn.v[i].row]) *dst++ = ',', len[hn.v[i].row]++;
+            memcpy(dst, hn.v[i].name, k + 1);
+            len[hn.v[i].row] += k;
+            free(hn.v[i].name);
         }
         free(len);
         *locus_names = out;
     }
-    free(hn);
-    free(qn[0]);
-    free(qn[1]);
+    free(hn.v);
+    for (int k = 0; k < 2; k++) {
+        free(side[k].qname);
+        free(side[k].xa);
+        free(side[k].nm);
+    }
     *eng_out = eng;
     *tab_out = tab;
 }

@@ -23,9 +23,10 @@ int main(int argc, char **argv)
     st.tid = malloc(cap * 4); st.pos = malloc(cap * 4); st.tmpend = malloc(cap * 4); st.mapq = malloc(cap); st.flag5 = malloc(cap);
     st.mpos = malloc(cap * 4); st.isize = malloc(cap * 4); st.hit_row = malloc(cap * 4); st.capacity = cap;
     char **qn = calloc(cap, sizeof(char *));
+    aln_side side = {1, 0, qn, NULL, NULL};
     int any_paired = 0, xa = 0;
     size_t n, total = 0;
-    while ((n = aln_read_batch(r, &st, cap, qn, &any_paired, &xa)) > 0) {
+    while ((n = aln_read_batch(r, &st, cap, &side, &any_paired, &xa)) > 0) {
         for (size_t i = 0; i < n; i++) {
             printf("%d\t%d\t%d\t%u\t%u\t%d\t%d\t%s\n", st.tid[i], st.pos[i], st.tmpend[i], st.mapq[i], st.flag5[i], st.mpos[i], st.isize[i], qn[i]);
             free(qn[i]);

@@ -230,9 +230,65 @@ def case_cfg1():
     emit_case("cfg1_chr22", t, r, runs, sam=False, with_seq=False)
 
 
+def case_sidechan():
+    """The host side channels: XA/NM tags (the multi-mapping veto, generic.c:303-341,972-982), exact duplicates (-R,
+    generic.c:907-919) and the bed outputs (-B/-V, generic.c:925-936)."""
+    chroms = [("chrA", 2000000), ("chrB", 500000)]
+    t = synth.make_table(301, chroms, 2500, n_names=120, n_fams=20, n_clas=7, overlap_frac=0.06, shuffle_frac=0.03)
+    header = chroms + [("chrZ", 20000)]
+    r = synth.make_reads(302, header, 6000, read_len=(30, 120), paired_frac=0.2, odd_cigar_frac=0.05)
+    rng = np.random.default_rng(303)
+    n = len(r)
+    # exact duplicates: a record repeats its predecessor's placement (same key chr:start:end:strand when both pass)
+    for i in rng.choice(np.arange(1, n), 900, replace=False):
+        for arr in (r.tid, r.pos, r.flag, r.l_qseq, r.mtid, r.mpos, r.isize):
+            arr[i] = arr[i - 1]
+        r.cigars[i] = list(r.cigars[i - 1])
+    r.mapq[:8] = 60            # -R looks its key buffer up before ever writing it when the file starts with MAPQ < Q records
+    # XA / NM on a third of the reads; alternatives land on repeats of the same name, of other names, on nothing,
+    # and on chromosomes without repeats or absent from every file
+    names = [nm for nm, _ in chroms]
+    aux = [[] for _ in range(n)]
+    for i in np.flatnonzero(rng.random(n) < 0.35):
+        nm = int(rng.integers(0, 4))
+        alts = []
+        for _ in range(int(rng.integers(1, 5))):
+            kind = rng.random()
+            if kind < 0.65:
+                row = int(rng.integers(0, len(t.start)))
+                c, p0 = names[int(t.chrom[row])], int(t.start[row]) + int(rng.integers(-20, 40))
+            elif kind < 0.85:
+                ci = int(rng.integers(0, 2))
+                c, p0 = names[ci], int(rng.integers(1, chroms[ci][1]))
+            elif kind < 0.93:
+                c, p0 = "chrZ", int(rng.integers(1, 20000))
+            else:
+                c, p0 = "chrNope", int(rng.integers(1, 5000))
+            alts.append(f"{c},{'+' if rng.random() < 0.5 else '-'}{max(p0, 1)},{int(r.l_qseq[i])}M,{int(rng.integers(0, 5))}")
+        fields = [f"XA:Z:{';'.join(alts)};"]
+        if rng.random() < 0.9:
+            fields.insert(0, f"NM:i:{nm}")
+        if rng.random() < 0.3:
+            fields.insert(0, "X0:i:1")
+        aux[i] = fields
+    r.aux = aux
+    runs = [
+        ("stat_veto", "stat", ["-w"], "reads.bam"),
+        ("stat_x", "stat", ["-w", "-x"], "reads.bam"),
+        ("stat_veto_sam", "stat", ["-w", "-S"], "reads.sam"),
+        ("stat_R", "stat", ["-w", "-R"], "reads.bam"),
+        ("stat_R_T_E0", "stat", ["-w", "-R", "-T", "-E", "0", "-x"], "reads.bam"),
+        ("stat_B_V", "stat", ["-w", "-B", "-V"], "reads.bam"),
+        ("stat_R_B_V_sam", "stat", ["-w", "-R", "-B", "-V", "-S", "-Q", "20"], "reads.sam"),
+        ("filter_R", "filter", ["-R", "-r"], "reads.bam"),
+        ("filter_xa_ignored", "filter", [], "reads.bam"),
+    ]
+    emit_case("sidechan", t, r, runs)
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -C oracle ref")
-    which = sys.argv[1:] or ["quirks", "mid", "manynames", "cfg1"]
+    which = sys.argv[1:] or ["quirks", "mid", "manynames", "cfg1", "sidechan"]
     for w in which:
         globals()["case_" + w]()

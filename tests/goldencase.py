@@ -36,7 +36,8 @@ def parse_opts(cmd, opts):
     """-> dict of engine parameters + output options, defaults from stat.c:34-36 / filter.c:37-41."""
     p = dict(mapq_min=10, min_cov=0.0001, extension=150, isize_max=500, treat_pe_as_se=False,
              discard_half_mapped=False, filter_mode=(cmd == "filter"), sam=False, add_chr=False, norm=0, norm2=0,
-             threshold=1, readlist=False, filter_field=0, filter_name="ALL", keep_wig=False, xa_off=False)
+             threshold=1, readlist=False, filter_field=0, filter_name="ALL", keep_wig=False, xa_off=False, dedup=False,
+             bed=False, bed_uniq=False)
     i = 0
     while i < len(opts):
         o = opts[i]
@@ -50,6 +51,9 @@ def parse_opts(cmd, opts):
         elif o == "-C": p["add_chr"] = True
         elif o == "-w": p["keep_wig"] = True
         elif o == "-x": p["xa_off"] = True
+        elif o == "-R": p["dedup"] = True
+        elif o == "-B": p["bed"] = True
+        elif o == "-V": p["bed_uniq"] = True
         elif o == "-N": p["norm"] = int(arg); i += 1
         elif o == "-U": p["norm2"] = int(arg); i += 1
         elif o == "-t": p["threshold"] = int(arg); i += 1
@@ -178,3 +182,96 @@ def loci_row_order(tm: TableModel):
         idx.sort(key=lambda k: (bin_of(tm.rows[k]["start"], tm.rows[k]["end"]), -k))
         order += idx
     return order
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The string / file-order parts of the reference's record loop, restated in Python for the small golden cases
+# (test infrastructure, like oracle/): which records leave through the -R `continue` (generic.c:907-919) and
+# through the XA veto (generic.c:303-341, 972-982). Returned as masks for the oracle's `skip`.
+
+def derive_py(p, tid2chrom, chrom_size, rd, i):
+    """generic.c:764-905 for record i -> (start, end, strand) as the loop holds them, or None when it is skipped."""
+    fl = int(rd["flag"][i])
+    if fl & refio.FUNMAP:
+        return None
+    t = int(rd["tid"][i])
+    c = int(tid2chrom[t]) if 0 <= t < len(tid2chrom) else -1
+    if c < 0:
+        return None
+    cend = refio.u32(int(chrom_size[c]) - 1)
+    if cend == 1:
+        return None
+    pos, tmpend, isz, mpos = int(rd["pos"][i]), int(rd["tmpend"][i]), int(rd["isize"][i]), int(rd["mpos"][i])
+    E = p["extension"]
+    se = True
+    if not p["treat_pe_as_se"] and (fl & 0x1):
+        if not (fl & 0x8):
+            if not (fl & 0x40) or abs(isz) > p["isize_max"] or isz == 0:
+                return None
+            se = False
+        elif p["discard_half_mapped"]:
+            return None
+    if se:
+        start, end = refio.u32(pos), min(cend, refio.u32(tmpend))
+        strand = "-" if fl & 0x10 else "+"
+        if E:
+            if strand == "+":
+                end = min(refio.u32(start + E), cend)
+            else:
+                start = 0 if end < E else end - E
+    elif isz > 0:
+        start = refio.u32(pos)
+        end, strand = min(cend, refio.u32(start + isz)), "+"
+    else:
+        start = refio.u32(mpos)
+        end, strand = min(cend, refio.u32(start - isz)), "-"
+    return start, end, strand
+
+
+def side_masks(p, tm, header, rd, ot, run_oracle):
+    """-> (dup_mask, veto_mask). run_oracle(skip) -> oracle result (for the chosen rows the veto looks at)."""
+    n = len(rd["tid"])
+    t2c = tid_map(header, tm, p["add_chr"])
+    names = [rename_chr(nm, p["add_chr"]) for nm, _ in header]
+    iv = [derive_py(p, t2c, tm.chrom_size, rd, i) for i in range(n)]
+    dup = np.zeros(n, bool)
+    if p["dedup"]:
+        seen, key = set(), None          # the reference's key buffer starts uninitialised; the goldens begin with MAPQ >= Q
+        for i in range(n):
+            if iv[i] is None:
+                continue
+            if int(rd["mapq"][i]) >= p["mapq_min"]:
+                key = "%s:%u:%u:%s" % (names[int(rd["tid"][i])], iv[i][0], iv[i][1], iv[i][2])
+            if key in seen:
+                dup[i] = True
+            else:
+                seen.add(key)
+    veto = np.zeros(n, bool)
+    if not p["filter_mode"] and not p["xa_off"] and rd.get("xa") is not None and any(x is not None for x in rd["xa"]):
+        first = run_oracle(dup)
+        cidx = {nm: i for i, nm in enumerate(tm.chrom_names)}
+        has_rows = set(int(c) for c in tm.chrom)
+        for i in range(n):
+            xa = rd["xa"][i]
+            row = int(first["hit_row"][i])
+            if xa is None or iv[i] is None or dup[i] or row < 0:
+                continue
+            chosen = tm.rows[row]["name"].upper()
+            qlen = refio.u32(iv[i][1] - iv[i][0])
+            qlen = qlen - (1 << 32) if qlen >= (1 << 31) else qlen                       # (int)qlen
+            fields = xa.split(";")[:100] if xa else []                                  # chopByChar, 100 slots
+            for alt in fields:
+                if not alt:
+                    continue
+                w = alt.split(",")
+                assert len(w) >= 4
+                if refio.strtol0(w[3]) > int(rd["nm"][i]):
+                    continue
+                s = abs(refio.strtol0(w[1]))
+                c = cidx.get(w[0])
+                if c is None or c not in has_rows:
+                    continue
+                if any(tm.rows[int(h)]["name"].upper() != chosen for h in ot.find(c, s, s + qlen)):
+                    veto[i] = True
+                    break
+    return dup, veto

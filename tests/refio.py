@@ -110,7 +110,7 @@ def read_sam(path):
     """SAM text -> core fields, following samtools-0.1.18's text parser where it matters here:
     a mapped record whose CIGAR is '*' is flagged unmapped (cussamtools/bam_import.c sam_read1)."""
     header, idx = [], {}
-    recs = {k: [] for k in ("tid", "pos", "tmpend", "mapq", "flag", "mpos", "isize", "qname")}
+    recs = {k: [] for k in ("tid", "pos", "tmpend", "mapq", "flag", "mpos", "isize", "qname", "xa", "nm")}
     with open_maybe_gz(path) as f:
         for line in f:
             if line.startswith("@"):
@@ -135,6 +135,11 @@ def read_sam(path):
             recs["mpos"].append(int(w[7]) - 1)
             recs["isize"].append(int(w[8]))
             recs["qname"].append(w[0])
+            # the first XA:Z and NM:i among the optional fields (bam_aux_get; bam_aux2i gives 0 without NM)
+            xa = next((x[5:] for x in w[11:] if x.startswith("XA:Z:")), None)
+            nm = next((int(x[5:]) for x in w[11:] if x.startswith("NM:i:")), 0)
+            recs["xa"].append(xa)
+            recs["nm"].append(nm if xa is not None else 0)
     return header, _to_arrays(recs)
 
 
@@ -142,7 +147,7 @@ def _to_arrays(recs):
     return {"tid": np.array(recs["tid"], np.int32), "pos": np.array(recs["pos"], np.int32),
             "tmpend": np.array(recs["tmpend"], np.int32), "mapq": np.array(recs["mapq"], np.uint8),
             "flag": np.array(recs["flag"], np.uint16), "mpos": np.array(recs["mpos"], np.int32),
-            "isize": np.array(recs["isize"], np.int32), "qname": recs["qname"]}
+            "isize": np.array(recs["isize"], np.int32), "qname": recs["qname"], "xa": recs.get("xa"), "nm": recs.get("nm")}
 
 
 def bgzf_decompress(data: bytes) -> bytes:
@@ -168,7 +173,7 @@ def read_bam(path):
         ln, = struct.unpack_from("<i", raw, off + 4 + l_name)
         header.append((name, ln))
         off += 8 + l_name
-    recs = {k: [] for k in ("tid", "pos", "tmpend", "mapq", "flag", "mpos", "isize", "qname")}
+    recs = {k: [] for k in ("tid", "pos", "tmpend", "mapq", "flag", "mpos", "isize", "qname", "xa", "nm")}
     cig_ops = "MIDNSHP=X"
     while off + 4 <= len(raw):
         bs, = struct.unpack_from("<i", raw, off)
@@ -192,8 +197,35 @@ def read_bam(path):
         recs["mpos"].append(mpos)
         recs["isize"].append(isize)
         recs["qname"].append(qname)
+        aux = _bam_aux(raw[p + 4 * n_cig + (l_seq + 1) // 2 + l_seq: off + 4 + bs])
+        recs["xa"].append(aux.get("XA"))
+        recs["nm"].append(int(aux.get("NM", 0)) if "XA" in aux else 0)
         off += 4 + bs
     return header, _to_arrays(recs)
+
+
+def _bam_aux(b: bytes):
+    """first value of every aux tag (cussamtools/bam_aux.c:36-48 walk)"""
+    out, i = {}, 0
+    fixed = {"A": "<c", "c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f", "d": "<d"}
+    while i + 3 <= len(b):
+        tag, ty = b[i:i + 2].decode(), chr(b[i + 2])
+        i += 3
+        if ty in fixed:
+            v, = struct.unpack_from(fixed[ty], b, i)
+            i += struct.calcsize(fixed[ty])
+        elif ty in "ZH":
+            j = b.index(b"\0", i)
+            v = b[i:j].decode()
+            i = j + 1
+        elif ty == "B":
+            sub, cnt = chr(b[i]), struct.unpack_from("<I", b, i + 1)[0]
+            i += 5 + cnt * struct.calcsize(fixed[sub])
+            v = None
+        else:
+            break
+        out.setdefault(tag, v)
+    return out
 
 
 # ------------------------------------------------------------------------------ outputs of the reference

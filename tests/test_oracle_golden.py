@@ -22,8 +22,16 @@ def _run_oracle(case, run):
                      [r["cons_start"] for r in tm.rows], [r["cons_end"] for r in tm.rows], tm.rep, tm.fam, tm.cla)
     assert (st == np.arange(len(tm.rows))).all()
     header, rd = gc.load_reads(case, run["aln"])
-    res = ot.run(p, gc.tid_map(header, tm, p["add_chr"]), rd["tid"], rd["pos"], rd["tmpend"], rd["mapq"], rd["flag"],
-                 rd["mpos"], rd["isize"])
+
+    def run_oracle(skip):
+        return ot.run(p, gc.tid_map(header, tm, p["add_chr"]), rd["tid"], rd["pos"], rd["tmpend"], rd["mapq"], rd["flag"],
+                      rd["mpos"], rd["isize"], skip=skip)
+    # -R and the XA veto are string / file-order logic outside the C restatement: their Python restatement
+    # (goldencase.side_masks) tells the oracle which records leave early, and owns the two counters they move
+    dup, veto = gc.side_masks(p, tm, header, rd, ot, run_oracle)
+    res = run_oracle(dup | veto)
+    res["cnt"][11] -= np.uint64(int((dup & (rd["mapq"] >= p["mapq_min"])).sum()))
+    res["cnt"][12] = np.uint64(int(veto.sum()))
     return p, tm, ot, rd, res
 
 

@@ -111,6 +111,7 @@ int main_stat(int argc, char **argv)
         free(first);
     }
     char *outWig = fmt_name(output, ".iteres.wig"), *outWigUniq = fmt_name(output, ".iteres.unique.wig");
+    char *outBigWig = fmt_name(output, ".iteres.bigWig"), *outBigWigUniq = fmt_name(output, ".iteres.unique.bigWig");
     char *outReport = fmt_name(output, ".iteres.report"), *outStat = fmt_name(output, ".iteres.subfamily.stat");
     char *outFam = fmt_name(output, ".iteres.family.stat"), *outCla = fmt_name(output, ".iteres.class.stat");
     int nindex = 0, nindex2 = 0;
@@ -164,10 +165,25 @@ int main_stat(int argc, char **argv)
     write_wig_and_stat(&rm, &res, cov_off, outStat, o.keep_wig ? outWig : NULL, outFam, outCla, o.keep_wig ? outWigUniq : NULL, cnt[nindex],
                        cnt[nindex2]);
 
-    /* stat.c:156-158 converts the two wigs to bigWig here; that writer (cuskent/bwgCreate.c) is the next row of the
-     * scope table and is not built yet — say so instead of leaving a silent gap */
+    /* stat.c:156-158: the two wigs as bigWig (written from the vectors, not by re-reading the text) */
     fprintf(stderr, "* Generating bigWig files\n");
-    fprintf(stderr, "  (bigWig output is not built into this version; use -w to keep the wig files)\n");
+    {
+        const char **nm = xcalloc((size_t)rm.reps.n + 1, sizeof *nm);
+        uint32_t *ln = xcalloc((size_t)rm.reps.n + 1, sizeof *ln);
+        const uint32_t **va = xcalloc((size_t)rm.reps.n + 1, sizeof *va), **vu = xcalloc((size_t)rm.reps.n + 1, sizeof *vu);
+        size_t k = 0;
+        for (uint32_t i = 0; i < rm.reps.n; i++)
+            if (rm.rep_len[i]) {
+                nm[k] = rm.reps.name[i];
+                ln[k] = rm.rep_len[i];
+                va[k] = res.cov + cov_off[i];
+                vu[k] = res.cov_uniq + cov_off[i];
+                k++;
+            }
+        write_bigwig(outBigWig, outWig, nm, ln, va, k);
+        write_bigwig(outBigWigUniq, outWigUniq, nm, ln, vu, k);
+        free(nm); free(ln); free(va); free(vu);
+    }
 
     fprintf(stderr, "* Preparing report file\n");
     write_report(outReport, cnt, o.mapq, "ALL");

@@ -133,6 +133,10 @@ void write_wig_and_stat(const rmsk_t *rm, const itx_result *res, const uint64_t 
 void write_filter_out(const rmsk_t *rm, const uint32_t *locus_cnt, char **locus_names, const char *path, int readlist, int threshold,
                       const char *subfam, unsigned long long reads_num);
 
+/* bigwig.c: the bigWig of one set of wig blocks (stat.c:156-158); only names with a consensus length belong here */
+void write_bigwig(const char *path, const char *wig_name, const char *const *names, const uint32_t *len, const uint32_t *const *val,
+                  size_t n_names);
+
 int main_stat(int argc, char **argv);
 int main_filter(int argc, char **argv);
 #endif

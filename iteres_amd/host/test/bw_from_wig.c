@@ -1,0 +1,48 @@
+/* bw_from_wig.c — test tool: feeds a text wig of "fixedStep chrom=<name> start=1 step=1 span=1" blocks to the
+ * product's bigWig writer (bigwig.c), so the writer can be checked on a machine without a GPU.
+ *   bw_from_wig <in.wig> <out.bigWig> */
+#define _GNU_SOURCE
+#include "../itx_host.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+int main(int argc, char **argv)
+{
+    if (argc != 3) {
+        fprintf(stderr, "usage: bw_from_wig <in.wig> <out.bigWig>\n");
+        return 2;
+    }
+    FILE *f = fopen(argv[1], "r");
+    if (!f) return 3;
+    char **names = NULL;
+    uint32_t *len = NULL, **val = NULL;
+    size_t n = 0, cap = 0, vcap = 0;
+    char *line = NULL;
+    size_t lcap = 0;
+    while (getline(&line, &lcap, f) >= 0) {
+        if (strncmp(line, "fixedStep", 9) == 0) {
+            if (n == cap) {
+                cap = cap ? cap * 2 : 64;
+                names = realloc(names, cap * sizeof *names);
+                len = realloc(len, cap * sizeof *len);
+                val = realloc(val, cap * sizeof *val);
+            }
+            const char *c = strstr(line, "chrom=") + 6;
+            names[n] = strndup(c, strcspn(c, " \t\n"));
+            len[n] = 0;
+            val[n] = NULL;
+            vcap = 0;
+            n++;
+        } else if (n && line[0] != '\n') {
+            if (len[n - 1] == vcap) {
+                vcap = vcap ? vcap * 2 : 1024;
+                val[n - 1] = realloc(val[n - 1], vcap * sizeof(uint32_t));
+            }
+            val[n - 1][len[n - 1]++] = (uint32_t)strtoul(line, NULL, 10);
+        }
+    }
+    fclose(f);
+    write_bigwig(argv[2], argv[1], (const char *const *)names, len, (const uint32_t *const *)val, n);
+    return 0;
+}

@@ -24,7 +24,11 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from iteres_amd import synth  # noqa: E402
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refio  # noqa: E402
+
 REF = os.path.join(ROOT, "oracle", "_ref", "iteres")
+KEEP_BIGWIG = {("quirks", "stat_default_bam")}
 GZ_OVER = 150_000   # outputs/inputs larger than this are stored gzipped
 
 
@@ -45,14 +49,20 @@ def run_ref(case_dir, run_name, cmd, opts, aln, tmp, prefix="out"):
     argv = [REF, cmd] + opts + ["-o", prefix, os.path.join(tmp, "chrom.sizes"), os.path.join(tmp, "rep.sizes"),
                                  os.path.join(tmp, "rmsk.txt"), os.path.join(tmp, aln)]
     pr = subprocess.run(argv, cwd=work, capture_output=True, text=True)
-    files = []
+    files, bigwigs = [], {}
     for fn in sorted(os.listdir(work)):
         if fn.endswith(".bigWig"):
+            # deflated by whatever zlib the reference was linked with: kept as a digest of the DECODED content
+            # (tests/refio.py bigwig_digest); the bytes themselves only for the runs named in KEEP_BIGWIG
+            raw = open(os.path.join(work, fn), "rb").read()
+            bigwigs[fn] = refio.bigwig_digest(raw)
+            if (os.path.basename(case_dir), run_name) in KEEP_BIGWIG:
+                shutil.copyfile(os.path.join(work, fn), os.path.join(out_dir, fn))
             continue
         _store(os.path.join(work, fn), os.path.join(out_dir, fn))
         files.append(fn)
     return {"name": run_name, "cmd": cmd, "opts": opts, "aln": aln, "prefix": prefix, "rc": pr.returncode,
-            "files": files, "stderr_tail": pr.stderr.replace("\r", "\n").strip().split("\n")[-3:]}
+            "files": files, "bigwig_sha256": bigwigs, "stderr_tail": pr.stderr.replace("\r", "\n").strip().split("\n")[-3:]}
 
 
 def emit_case(name, table, reads, runs, extra_rmsk_rows=(), extra_chrom_sizes=(), bam=True, sam=True, with_seq=True):

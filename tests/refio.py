@@ -289,3 +289,97 @@ def kent_hash_order(names_in_insertion_order, power=12):
             size *= 2
     keyed = [((kent_hash_string(nm) & (size - 1)), -i, nm) for i, nm in enumerate(names_in_insertion_order)]
     return [nm for _, _, nm in sorted(keyed)]
+
+
+# ------------------------------------------------------------------------------ bigWig (decoded content)
+
+def bigwig_decode(data: bytes):
+    """Decodes a bigWig into what it says, independent of how its blocks were deflated: chromosomes (walking the
+    B+ tree), the data sections and the zoom records (walking the R trees, inflating every block), the zoom
+    reductions and the file-wide summary. Format as written by cuskent/bwgCreate.c:887-1019."""
+    sig, version, n_zoom, chrom_off, data_off, index_off, fcnt, dfcnt, asql, total_off, unc_buf, _ = struct.unpack_from("<IHHQQQHHQQIQ", data, 0)
+    assert sig == 0x888FFC26 and struct.unpack_from("<I", data, len(data) - 4)[0] == sig
+    zooms = [struct.unpack_from("<IIQQ", data, 64 + 24 * i) for i in range(n_zoom)]
+    total = struct.unpack_from("<Qdddd", data, total_off) if total_off else None
+
+    # chromosome B+ tree (cuskent/bPlusTree.c)
+    magic, bsize, ksize, vsize, n_items, _ = struct.unpack_from("<IIIIQQ", data, chrom_off)
+    assert magic == 0x78CA8C91 and vsize == 8
+    chroms = []
+
+    def walk_bpt(off):
+        is_leaf, _, cnt = struct.unpack_from("<BBH", data, off)
+        off += 4
+        for i in range(cnt):
+            key = data[off:off + ksize].split(b"\0", 1)[0].decode()
+            if is_leaf:
+                cid, size = struct.unpack_from("<II", data, off + ksize)
+                chroms.append((key, cid, size))
+                off += ksize + 8
+            else:
+                child, = struct.unpack_from("<Q", data, off + ksize)
+                walk_bpt(child)
+                off += ksize + 8
+    walk_bpt(chrom_off + 32)
+    assert len(chroms) == n_items
+
+    def walk_cir(off):
+        """leaf items (start chrom, start base, end chrom, end base, offset, size) in tree order"""
+        magic, bs, cnt, sc, sb, ec, eb, end_off, per_slot, _ = struct.unpack_from("<IIQIIIIQII", data, off)
+        assert magic == 0x2468ACE0
+        out = []
+
+        def rec(o):
+            is_leaf, _, n = struct.unpack_from("<BBH", data, o)
+            o += 4
+            for i in range(n):
+                if is_leaf:
+                    out.append(struct.unpack_from("<IIIIQQ", data, o))
+                    o += 32
+                else:
+                    child, = struct.unpack_from("<Q", data, o + 16)
+                    rec(child)
+                    o += 24
+        rec(off + 48)
+        return {"block_size": bs, "item_count": cnt, "bounds": (sc, sb, ec, eb), "items_per_slot": per_slot}, out
+
+    n_sections, = struct.unpack_from("<Q", data, data_off)
+    idx_head, leaves = walk_cir(index_off)
+    sections = []
+    for sc, sb, ec, eb, off, size in leaves:
+        raw = zlib.decompress(data[off:off + size])
+        cid, start, end, step, span, typ, _, cnt = struct.unpack_from("<IIIIIBBH", raw, 0)
+        assert (sc, sb, ec, eb) == (cid, start, cid, end) and typ == 3 and len(raw) == 24 + 4 * cnt
+        sections.append((cid, start, end, step, span, typ, raw[24:]))
+    assert len(sections) == n_sections == idx_head["item_count"]
+    zoom_out = []
+    for red, _, zdata, zindex in zooms:
+        cnt, = struct.unpack_from("<I", data, zdata)
+        zh, zl = walk_cir(zindex)
+        recs = b"".join(zlib.decompress(data[off:off + size]) for _, _, _, _, off, size in zl)
+        assert len(recs) == 32 * cnt == 32 * zh["item_count"]
+        zoom_out.append((red, zh["bounds"], recs))
+    return {"version": version, "field_counts": (fcnt, dfcnt, asql), "uncompress_buf": unc_buf, "total": total, "chroms": chroms,
+            "index": idx_head, "sections": sections, "zooms": zoom_out}
+
+
+def bigwig_digest(data: bytes) -> str:
+    import hashlib
+    d = bigwig_decode(data)
+    h = hashlib.sha256()
+    h.update(repr((d["version"], d["field_counts"], d["uncompress_buf"], d["total"], d["chroms"], sorted(d["index"].items()))).encode())
+    for s in d["sections"]:
+        h.update(struct.pack("<IIIIIB", *s[:6]) + s[6])
+    for red, bounds, recs in d["zooms"]:
+        h.update(struct.pack("<IIIII", red, *bounds) + recs)
+    return h.hexdigest()
+
+
+def bigwig_values(data: bytes):
+    """{chromosome name: float32 array} of the per-base values"""
+    d = bigwig_decode(data)
+    names = {cid: (nm, size) for nm, cid, size in d["chroms"]}
+    out = {nm: np.zeros(size, np.float32) for nm, size in names.values()}
+    for cid, start, end, step, span, typ, raw in d["sections"]:
+        out[names[cid][0]][start:end] = np.frombuffer(raw, "<f4")
+    return out

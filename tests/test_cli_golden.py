@@ -37,6 +37,12 @@ def test_cli_matches_reference_files(case, run_name, exe, tmp_path):
         assert got_path.exists(), f"{fn} missing; stderr: {pr.stderr[-1500:]}"
         got = got_path.read_bytes()
         assert got == want, f"{case}/{run_name}/{fn} differs"
+    # bigWig (stat.c:156-158): same decoded content as the reference's file — chromosomes, sections, zoom records,
+    # summary (tests/refio.py bigwig_digest; the deflate bytes depend on the zlib at hand)
+    for fn, want in run.get("bigwig_sha256", {}).items():
+        got_path = work / fn
+        assert got_path.exists(), f"{fn} missing"
+        assert refio.bigwig_digest(got_path.read_bytes()) == want, f"{case}/{run_name}/{fn}: decoded bigWig differs"
     # the banners the reference prints around the phases are part of the boundary too
     err = pr.stderr.replace("\r", "\n")
     if run["cmd"] == "stat":

@@ -102,34 +102,75 @@ static void add_to_summary(bw_sumlist *L, uint32_t chrom_id, uint32_t chrom_size
     }
 }
 
-/* cuskent/bwgCreate.c:751-795: every base of every section, as a one-base range (bbiAddRangeToSummary, bbiWrite.c:424-433) */
-static bw_sumlist reduce_sections(const bw_section *sec, size_t n_sec, const bw_chrom *chroms, int reduction)
+/* Summaries never span two chromosomes (a new one starts whenever the chromosome id changes, bbiWrite.c:381), so the
+ * chromosomes are reduced independently, in parallel, and their lists joined in order: same numbers, same order. */
+static void sumlist_join(bw_sumlist *out, bw_sumlist *parts, size_t n_parts)
 {
-    bw_sumlist L = {NULL, 0, 0};
-    for (size_t k = 0; k < n_sec; k++) {
-        const uint32_t chrom_size = chroms[sec[k].chrom_id].size;
-        uint32_t start = sec[k].start;
-        for (uint32_t i = 0; i < sec[k].item_count; i++) {
-            const double val = (double)(float)(double)sec[k].val[i];          /* "%u" text -> double -> the float a section stores */
-            const int size = 1;
-            const double sum = size * val;
-            add_to_summary(&L, sec[k].chrom_id, chrom_size, start, start + 1, (uint32_t)size, val, val, sum, sum * val, reduction);
-            start += 1;
-        }
+    size_t total = 0;
+    for (size_t i = 0; i < n_parts; i++) total += parts[i].n;
+    out->v = xmalloc((total ? total : 1) * sizeof *out->v);
+    out->n = out->cap = total;
+    size_t at = 0;
+    for (size_t i = 0; i < n_parts; i++) {
+        if (parts[i].n) memcpy(out->v + at, parts[i].v, parts[i].n * sizeof *out->v);
+        at += parts[i].n;
+        free(parts[i].v);
     }
-    return L;
+    free(parts);
+}
+
+/* cuskent/bwgCreate.c:751-795: every base of every section, as a one-base range (bbiAddRangeToSummary, bbiWrite.c:424-433).
+ * sec_of[c] .. sec_of[c+1]: the sections of chromosome c. */
+static bw_sumlist reduce_sections(const bw_section *sec, const size_t *sec_of, const bw_chrom *chroms, size_t n_chroms, int reduction)
+{
+    bw_sumlist *parts = xcalloc(n_chroms ? n_chroms : 1, sizeof *parts);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (long c = 0; c < (long)n_chroms; c++) {
+        bw_sumlist L = {NULL, 0, 0};
+        for (size_t k = sec_of[c]; k < sec_of[c + 1]; k++) {
+            const uint32_t chrom_size = chroms[sec[k].chrom_id].size;
+            uint32_t start = sec[k].start;
+            for (uint32_t i = 0; i < sec[k].item_count; i++) {
+                const double val = (double)(float)(double)sec[k].val[i];      /* "%u" text -> double -> the float a section stores */
+                const int size = 1;
+                const double sum = size * val;
+                add_to_summary(&L, sec[k].chrom_id, chrom_size, start, start + 1, (uint32_t)size, val, val, sum, sum * val, reduction);
+                start += 1;
+            }
+        }
+        parts[c] = L;
+    }
+    bw_sumlist out;
+    sumlist_join(&out, parts, n_chroms);
+    return out;
 }
 
 /* cuskent/bbiWrite.c:435-446 */
-static bw_sumlist reduce_summaries(const bw_sumlist *in, const bw_chrom *chroms, int reduction)
+static bw_sumlist reduce_summaries(const bw_sumlist *in, const bw_chrom *chroms, size_t n_chroms, int reduction)
 {
-    bw_sumlist L = {NULL, 0, 0};
-    for (size_t i = 0; i < in->n; i++) {
-        const bw_summary *s = &in->v[i];
-        add_to_summary(&L, s->chrom_id, chroms[s->chrom_id].size, s->start, s->end, s->valid_count, s->min_val, s->max_val, s->sum_data,
-                       s->sum_squares, reduction);
+    /* first summary of every chromosome in the input list (ids ascend) */
+    size_t *first = xcalloc(n_chroms + 2, sizeof *first);
+    {
+        size_t c = 0;
+        for (size_t i = 0; i < in->n; i++)
+            while (c <= in->v[i].chrom_id) first[c++] = i;
+        while (c <= n_chroms) first[c++] = in->n;
     }
-    return L;
+    bw_sumlist *parts = xcalloc(n_chroms ? n_chroms : 1, sizeof *parts);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (long c = 0; c < (long)n_chroms; c++) {
+        bw_sumlist L = {NULL, 0, 0};
+        for (size_t i = first[c]; i < first[c + 1]; i++) {
+            const bw_summary *s = &in->v[i];
+            add_to_summary(&L, s->chrom_id, chroms[s->chrom_id].size, s->start, s->end, s->valid_count, s->min_val, s->max_val, s->sum_data,
+                           s->sum_squares, reduction);
+        }
+        parts[c] = L;
+    }
+    free(first);
+    bw_sumlist out;
+    sumlist_join(&out, parts, n_chroms);
+    return out;
 }
 
 /* ---- cuskent/zlibFace.c:37-56 */
@@ -356,36 +397,51 @@ static uint64_t write_summary_and_index(FILE *f, bw_sumlist *L, uint32_t block_s
     const uint32_t count = (uint32_t)L->n;
     PUT(f, count);
     const size_t unc_cap = 32 * (size_t)items_per_slot, comp_cap = z_buf_size(unc_cap);
-    char *unc = xmalloc(unc_cap), *comp = xmalloc(comp_cap);
     ritem *items = xcalloc(count ? count : 1, sizeof *items);
-    for (uint32_t i = 0; i < count;) {
-        const uint32_t in_slot = count - i > items_per_slot ? items_per_slot : count - i;
-        const uint64_t pos = (uint64_t)ftello(f);
-        char *w = unc;
-        for (uint32_t k = 0; k < in_slot; k++) {
-            bw_summary *s = &L->v[i + k];
-            memcpy(w, &s->chrom_id, 4); w += 4;
-            memcpy(w, &s->start, 4); w += 4;
-            memcpy(w, &s->end, 4); w += 4;
-            memcpy(w, &s->valid_count, 4); w += 4;
-            memcpy(w, &s->min_val, 4); w += 4;
-            memcpy(w, &s->max_val, 4); w += 4;
-            memcpy(w, &s->sum_data, 4); w += 4;
-            memcpy(w, &s->sum_squares, 4); w += 4;
-            s->file_offset = pos;
-            items[i + k].chrom = s->chrom_id;
-            items[i + k].start = s->start;
-            items[i + k].end = s->end;
-            items[i + k].off = pos;
+    /* slots are deflated in parallel into memory, then laid down in order */
+    const size_t n_slots = ((size_t)count + items_per_slot - 1) / items_per_slot, group = 1024;
+    char *comp = xmalloc(comp_cap * group);
+    size_t *csize = xcalloc(group, sizeof *csize);
+    for (size_t g0 = 0; g0 < n_slots; g0 += group) {
+        const size_t g1 = g0 + group < n_slots ? g0 + group : n_slots;
+#pragma omp parallel for schedule(dynamic, 4)
+        for (long sl = (long)g0; sl < (long)g1; sl++) {
+            const uint32_t i = (uint32_t)sl * items_per_slot;
+            const uint32_t in_slot = count - i > items_per_slot ? items_per_slot : count - i;
+            char *unc = xmalloc(unc_cap), *w = unc;
+            for (uint32_t k = 0; k < in_slot; k++) {
+                const bw_summary *s = &L->v[i + k];
+                memcpy(w, &s->chrom_id, 4); w += 4;
+                memcpy(w, &s->start, 4); w += 4;
+                memcpy(w, &s->end, 4); w += 4;
+                memcpy(w, &s->valid_count, 4); w += 4;
+                memcpy(w, &s->min_val, 4); w += 4;
+                memcpy(w, &s->max_val, 4); w += 4;
+                memcpy(w, &s->sum_data, 4); w += 4;
+                memcpy(w, &s->sum_squares, 4); w += 4;
+            }
+            csize[sl - (long)g0] = z_compress(unc, (size_t)(w - unc), comp + (size_t)(sl - (long)g0) * comp_cap, comp_cap);
+            free(unc);
         }
-        const size_t cs = z_compress(unc, (size_t)(w - unc), comp, comp_cap);
-        put(f, comp, cs);
-        i += in_slot;
+        for (size_t sl = g0; sl < g1; sl++) {
+            const uint32_t i = (uint32_t)sl * items_per_slot;
+            const uint32_t in_slot = count - i > items_per_slot ? items_per_slot : count - i;
+            const uint64_t pos = (uint64_t)ftello(f);
+            for (uint32_t k = 0; k < in_slot; k++) {
+                bw_summary *s = &L->v[i + k];
+                s->file_offset = pos;
+                items[i + k].chrom = s->chrom_id;
+                items[i + k].start = s->start;
+                items[i + k].end = s->end;
+                items[i + k].off = pos;
+            }
+            put(f, comp + (sl - g0) * comp_cap, csize[sl - g0]);
+        }
     }
+    free(csize);
     const uint64_t index_offset = (uint64_t)ftello(f);
     cir_tree_write(f, items, count, block_size, items_per_slot, index_offset);
     free(items);
-    free(unc);
     free(comp);
     return index_offset;
 }
@@ -396,10 +452,23 @@ static int cmp_chrom_name(const void *a, const void *b)
 }
 
 /* names[i] / len[i] / val[i]: the wig blocks (only names with len != 0 belong here, generic.c:83-90) */
+#include <time.h>
+static double bw_t0;
+static void bw_tick(const char *what)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    if (getenv("ITX_TIMING_BW")) fprintf(stderr, "[bw] %s %.3f\n", what, t - bw_t0);
+    bw_t0 = t;
+}
+#define BW_T(x) bw_tick(x)
+
 void write_bigwig(const char *path, const char *wig_name, const char *const *names, const uint32_t *len, const uint32_t *const *val,
                   size_t n_names)
 {
     const uint32_t block_size = 256, items_per_slot = 1024;                  /* stat.c:157-158 */
+    BW_T("start");
     if (n_names == 0) die("%s is empty of data", wig_name);                  /* bwgCreate.c:1108-1109 */
     /* chromosomes in strcmp order (the section sort, bwgCreate.c:138-151), ids in that order (:584-627) */
     bw_chrom *chroms = xcalloc(n_names, sizeof *chroms);
@@ -420,9 +489,11 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
         n_sec += (chroms[i].size + items_per_slot - 1) / items_per_slot;
     }
     bw_section *sec = xcalloc(n_sec ? n_sec : 1, sizeof *sec);
+    size_t *sec_of = xcalloc(n_names + 1, sizeof *sec_of);
     size_t k = 0;
     uint64_t full_size = 0;
-    for (size_t i = 0; i < n_names; i++)
+    for (size_t i = 0; i < n_names; i++) {
+        sec_of[i] = k;
         for (uint32_t s = 0; s < chroms[i].size; s += items_per_slot) {
             const uint32_t c = chroms[i].size - s > items_per_slot ? items_per_slot : chroms[i].size - s;
             sec[k].chrom_id = (uint32_t)i;
@@ -433,7 +504,10 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
             full_size += 24 + 4 * (uint64_t)c;
             k++;
         }
+    }
+    sec_of[n_names] = k;
 
+    BW_T("sections");
     /* zoom levels (bwgCreate.c:826-885): step 1 everywhere, so the average resolution is 1 and the first try is 10 */
     int initial_reduction = 1 * 10;
     const uint64_t max_reduced = full_size / 2;
@@ -441,7 +515,7 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
     bw_sumlist sums[10];
     uint32_t reductions[10];
     for (;;) {
-        sums[0] = reduce_sections(sec, n_sec, chroms, initial_reduction);
+        sums[0] = reduce_sections(sec, sec_of, chroms, n_names, initial_reduction);
         uint64_t size = (uint64_t)sums[0].n * 32;
         size *= 2;                                                             /* "summary not compressing as well as primary data" */
         if (size >= max_reduced && size != last_summary_size) {
@@ -459,7 +533,7 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
     for (int i = 0; i < 9; i++) {
         reduction *= 4;
         if (reduction > 1000000000) break;
-        bw_sumlist L = reduce_summaries(&sums[n_sums - 1], chroms, (int)reduction);
+        bw_sumlist L = reduce_summaries(&sums[n_sums - 1], chroms, n_names, (int)reduction);
         const uint64_t size = (uint64_t)L.n * 32;
         const size_t items = L.n;
         if (size != last_summary_size) {
@@ -471,6 +545,7 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
         if (items <= n_names) break;
     }
 
+    BW_T("zoom lists");
     FILE *f = fopen(path, "wb");
     if (!f) die("mustOpen: Can't open %s to write: %s", path, strerror(errno));
     const uint32_t sig = BW_SIG, res32 = 0;
@@ -511,36 +586,49 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
     const uint64_t section_count = n_sec;
     PUT(f, section_count);
     {
+        /* sections are deflated in parallel into memory, then laid down in order (their offsets feed the index) */
         const size_t cap = 24 + 4 * (size_t)items_per_slot, ccap = z_buf_size(cap);
-        char *buf = xmalloc(cap), *comp = xmalloc(ccap);
-        for (size_t i = 0; i < n_sec; i++) {
-            bw_section *s = &sec[i];
-            const uint32_t step = 1, span = 1;
-            const uint8_t type = 3, r8 = 0;                                    /* bwgTypeFixedStep */
-            const uint16_t cnt = (uint16_t)s->item_count;
-            char *w = buf;
-            s->file_offset = (uint64_t)ftello(f);
-            memcpy(w, &s->chrom_id, 4); w += 4;
-            memcpy(w, &s->start, 4); w += 4;
-            memcpy(w, &s->end, 4); w += 4;
-            memcpy(w, &step, 4); w += 4;
-            memcpy(w, &span, 4); w += 4;
-            memcpy(w, &type, 1); w += 1;
-            memcpy(w, &r8, 1); w += 1;
-            memcpy(w, &cnt, 2); w += 2;
-            for (uint32_t j = 0; j < s->item_count; j++) {
-                const float v = (float)(double)s->val[j];
-                memcpy(w, &v, 4);
-                w += 4;
+        const size_t group = 4096;
+        char *comp = xmalloc(ccap * group);
+        size_t *csize = xcalloc(group, sizeof *csize);
+        for (size_t g0 = 0; g0 < n_sec; g0 += group) {
+            const size_t g1 = g0 + group < n_sec ? g0 + group : n_sec;
+            uint32_t unc_max = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(max : unc_max)
+            for (long i = (long)g0; i < (long)g1; i++) {
+                const bw_section *s = &sec[i];
+                const uint32_t step = 1, span = 1;
+                const uint8_t type = 3, r8 = 0;                                /* bwgTypeFixedStep */
+                const uint16_t cnt = (uint16_t)s->item_count;
+                char buf[24 + 4 * 1024];
+                char *w = buf;
+                memcpy(w, &s->chrom_id, 4); w += 4;
+                memcpy(w, &s->start, 4); w += 4;
+                memcpy(w, &s->end, 4); w += 4;
+                memcpy(w, &step, 4); w += 4;
+                memcpy(w, &span, 4); w += 4;
+                memcpy(w, &type, 1); w += 1;
+                memcpy(w, &r8, 1); w += 1;
+                memcpy(w, &cnt, 2); w += 2;
+                for (uint32_t j = 0; j < s->item_count; j++) {
+                    const float v = (float)(double)s->val[j];
+                    memcpy(w, &v, 4);
+                    w += 4;
+                }
+                const uint32_t unc = (uint32_t)(w - buf);
+                if (unc > unc_max) unc_max = unc;
+                csize[i - (long)g0] = z_compress(buf, unc, comp + (size_t)(i - (long)g0) * ccap, ccap);
             }
-            const uint32_t unc = (uint32_t)(w - buf);
-            if (unc > unc_buf) unc_buf = unc;
-            const size_t cs = z_compress(buf, unc, comp, ccap);
-            put(f, comp, cs);
+            if (unc_max > unc_buf) unc_buf = unc_max;
+            for (size_t i = g0; i < g1; i++) {
+                sec[i].file_offset = (uint64_t)ftello(f);
+                put(f, comp + (i - g0) * ccap, csize[i - g0]);
+            }
         }
-        free(buf);
         free(comp);
+        free(csize);
     }
+    BW_T("data");
     index_off = (uint64_t)ftello(f);
     {
         ritem *items = xcalloc(n_sec ? n_sec : 1, sizeof *items);
@@ -553,11 +641,13 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
         cir_tree_write(f, items, n_sec, block_size, 1, index_off);
         free(items);
     }
+    BW_T("index");
     uint64_t zoom_data[10], zoom_index[10];
     for (int i = 0; i < n_sums; i++) {
         zoom_data[i] = (uint64_t)ftello(f);
         zoom_index[i] = write_summary_and_index(f, &sums[i], block_size, items_per_slot);
     }
+    BW_T("zooms");
     /* the file-wide summary from the first zoom level (bwgCreate.c:966-988) */
     if (sums[0].n) {
         const bw_summary *s = &sums[0].v[0];
@@ -600,6 +690,7 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
     if (fclose(f) != 0) die("carefulClose: error closing %s", path);
     for (int i = 0; i < n_sums; i++) free(sums[i].v);
     free(sec);
+    free(sec_of);
     free(src);
     free(chroms);
 }

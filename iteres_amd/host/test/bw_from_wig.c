@@ -6,6 +6,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 int main(int argc, char **argv)
 {
@@ -43,6 +44,10 @@ int main(int argc, char **argv)
         }
     }
     fclose(f);
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     write_bigwig(argv[2], argv[1], (const char *const *)names, len, (const uint32_t *const *)val, n);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (getenv("ITX_TIMING")) fprintf(stderr, "[itx timing] write_bigwig %.3f s\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
     return 0;
 }

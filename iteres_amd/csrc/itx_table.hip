@@ -21,7 +21,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <atomic>
 #include <numeric>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 static thread_local char g_err[512];
@@ -60,6 +64,24 @@ static bool bin_of_range(int start, int end, int *level, int *bin)
         eb >>= 3;
     }
     return false;
+}
+
+// Runs fn(c) for every chromosome on a few host threads (chromosomes are independent in every sort below).
+template <class F>
+static void for_each_chrom(int n_chrom, F fn)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    if ((int)nt > n_chrom) nt = n_chrom > 0 ? (unsigned)n_chrom : 1u;
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (int c = next.fetch_add(1); c < n_chrom; c = next.fetch_add(1)) fn(c);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
 }
 
 struct Carver {
@@ -110,22 +132,45 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         }
         chrom_cnt[r.chrom + 1]++;
     }
-    // units: distinct (rep, fam, cla) triples, ordered by (rep, fam, cla)
-    std::vector<uint32_t> uorder(n_rows);
-    std::iota(uorder.begin(), uorder.end(), 0u);
-    std::sort(uorder.begin(), uorder.end(), [&](uint32_t a, uint32_t b) {
-        const itx_row &x = rows[a], &y = rows[b];
-        if (x.rep != y.rep) return x.rep < y.rep;
-        if (x.fam != y.fam) return x.fam < y.fam;
-        return x.cla < y.cla;
-    });
+    // units: distinct (rep, fam, cla) triples, ordered by (rep, fam, cla). There are few of them (tens of thousands for
+    // rmsk): collect the distinct triples through a hash, sort those, then one lookup per row.
     std::vector<uint32_t> unit_of_row(n_rows);
     std::vector<uint4> unit_ids;
-    for (size_t k = 0; k < n_rows; k++) {
-        const itx_row &r = rows[uorder[k]];
-        if (k == 0 || unit_ids.back().x != r.rep || unit_ids.back().y != r.fam || unit_ids.back().z != r.cla)
-            unit_ids.push_back(make_uint4(r.rep, r.fam, r.cla, 0));
-        unit_of_row[uorder[k]] = (uint32_t)unit_ids.size() - 1;
+    {
+        struct TripleHash {
+            size_t operator()(const std::array<uint32_t, 3> &k) const
+            {
+                uint64_t h = ((uint64_t)k[0] * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)k[1] << 32 | k[2]) * 0xc2b2ae3d27d4eb4full;
+                return (size_t)(h ^ (h >> 29));
+            }
+        };
+        std::unordered_map<std::array<uint32_t, 3>, uint32_t, TripleHash> seen;
+        seen.reserve(1 << 16);
+        std::array<uint32_t, 3> last = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+        uint32_t last_id = 0;
+        std::vector<std::array<uint32_t, 3>> triples;
+        for (size_t i = 0; i < n_rows; i++) {                       // provisional ids in first-seen order
+            const std::array<uint32_t, 3> k = {rows[i].rep, rows[i].fam, rows[i].cla};
+            if (k != last) {
+                auto it = seen.find(k);
+                if (it == seen.end()) {
+                    it = seen.emplace(k, (uint32_t)triples.size()).first;
+                    triples.push_back(k);
+                }
+                last = k;
+                last_id = it->second;
+            }
+            unit_of_row[i] = last_id;
+        }
+        std::vector<uint32_t> ord(triples.size()), final_id(triples.size());
+        std::iota(ord.begin(), ord.end(), 0u);
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return triples[a] < triples[b]; });
+        unit_ids.resize(triples.size());
+        for (size_t k = 0; k < ord.size(); k++) {
+            final_id[ord[k]] = (uint32_t)k;
+            unit_ids[k] = make_uint4(triples[ord[k]][0], triples[ord[k]][1], triples[ord[k]][2], 0);
+        }
+        for (size_t i = 0; i < n_rows; i++) unit_of_row[i] = final_id[unit_of_row[i]];
     }
     const uint32_t n_units = (uint32_t)unit_ids.size();
     std::vector<uint64_t> covoff(n_rep + 1);
@@ -160,14 +205,15 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         std::vector<uint32_t> fill(chrom_off.begin(), chrom_off.end() - 1);
         for (size_t i = 0; i < n_rows; i++) order[fill[rows[i].chrom]++] = (uint32_t)i;
     }
-    for (int c = 0; c < n_chrom; c++)
+    for_each_chrom(n_chrom, [&](int c) {
         std::stable_sort(order.begin() + chrom_off[c], order.begin() + chrom_off[c + 1],
                          [&](uint32_t a, uint32_t b) { return (int)rows[a].start < (int)rows[b].start; });
+    });
     // rank in binKeeperFind's return order: level coarse (5) -> fine (0), bin descending, file order ascending
     std::vector<uint32_t> rank_of_row(n_rows);
     {
         std::vector<uint32_t> canon(n_rows);
-        for (int c = 0; c < n_chrom; c++) {
+        for_each_chrom(n_chrom, [&](int c) {
             uint32_t lo = chrom_off[c], hi = chrom_off[c + 1];
             std::copy(order.begin() + lo, order.begin() + hi, canon.begin() + lo);
             std::sort(canon.begin() + lo, canon.begin() + hi, [&](uint32_t a, uint32_t b) {
@@ -176,7 +222,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
                 return a < b;
             });
             for (uint32_t k = lo; k < hi; k++) rank_of_row[canon[k]] = k - lo;
-        }
+        });
     }
     // bin width: about one row per bin (128 bp .. 128 kb)
     uint64_t genome = 0;
@@ -190,7 +236,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     std::vector<ItxIv> iv(n_rows);
     std::vector<int32_t> orig(n_rows);
     std::vector<int32_t> csize(n_chrom);
-    for (int c = 0; c < n_chrom; c++) {
+    for_each_chrom(n_chrom, [&](int c) {
         csize[c] = (int32_t)chrom_size[c];
         uint32_t lo = chrom_off[c], hi = chrom_off[c + 1];
         int32_t pm = INT32_MIN;
@@ -219,7 +265,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
             while (m < hi && (int64_t)pmax(m) <= bound) m++;         // first row whose prefix-max end passes the bin start
             bl[bin_off[c] + b] = make_uint2(k, m);
         }
-    }
+    });
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {

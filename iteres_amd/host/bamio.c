@@ -7,13 +7,27 @@
 #include "itx_host.h"
 
 #include <ctype.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
 #define BGZF_MAX 0x10000
 
+#include <time.h>
+static double t_io, t_inflate, t_hop, t_parse;          /* ITX_TIMING: where the decoder's wall time goes */
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static uint32_t rd_u32_at(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+struct blk {
+    size_t coff, csize, uoff, usize;
+};
 
 struct aln_reader {
     FILE *f;
@@ -32,6 +46,15 @@ struct aln_reader {
     size_t *rec_off;          /* start of every complete record in ubuf                                        */
     size_t n_rec, rec_next, rec_cap;
     int eof;                  /* no more compressed input (end of file or a damaged block)                     */
+    struct blk *blk;          /* block index of the chunk being inflated                                        */
+    size_t blk_cap;
+    /* read-ahead (bgzf_load_chunk): spare buffer the loader thread inflates the next chunk into */
+    uint8_t *nbuf;
+    size_t ncap, nlen;
+    int n_eof, pf_on, pf_state, pf_stop;       /* pf_state: 0 idle, 1 requested, 2 ready */
+    pthread_t pf_thread;
+    pthread_mutex_t pf_mu;
+    pthread_cond_t pf_cv;
     /* SAM state */
     char *line;
     size_t line_cap;
@@ -40,11 +63,19 @@ struct aln_reader {
 };
 
 /* ---- BGZF ------------------------------------------------------------------------------------------------ */
-#define CHUNK_COMPRESSED (48u << 20)
-
-struct blk {
-    size_t coff, csize, uoff, usize;
-};
+#define CHUNK_COMPRESSED_DEFAULT (48u << 20)
+/* compressed bytes read and inflated per step; ITX_BGZF_CHUNK overrides it (tests force many small steps) */
+static size_t chunk_compressed(void)
+{
+    static size_t v;
+    if (!v) {
+        const char *e = getenv("ITX_BGZF_CHUNK");
+        const long x = e ? atol(e) : 0;
+        v = x >= 1 ? (size_t)x : CHUNK_COMPRESSED_DEFAULT;
+    }
+    return v;
+}
+#define CHUNK_COMPRESSED chunk_compressed()
 
 /* bgzf.c:401-411 check_header: gzip member with exactly one 6-byte extra field "BC" */
 static int bgzf_header_ok(const uint8_t *h)
@@ -67,30 +98,25 @@ static int inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t 
     return (rc == Z_STREAM_END && zs.total_out == usize) ? 0 : -1;
 }
 
-/* Reads the next chunk of compressed blocks, inflates them in parallel behind the unconsumed bytes of ubuf.
- * Returns the number of bytes added (0 at end of input). */
-static size_t bgzf_load_chunk(aln_reader *r)
+/* Reads the next chunk of compressed blocks and inflates them in parallel into *pbuf at offset `at` (the buffer is
+ * grown as needed, bytes before `at` are kept). Returns the number of bytes inflated; *peof is set when there is no
+ * more input (end of file or a damaged block). Touches only the compressed-side state of the reader. */
+static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, size_t at, int *peof)
 {
-    if (r->eof) return 0;
-    /* keep what the record parser has not consumed */
-    if (r->upos) {
-        memmove(r->ubuf, r->ubuf + r->upos, r->ulen - r->upos);
-        r->ulen -= r->upos;
-        r->upos = 0;
-    }
     if (r->ccap < CHUNK_COMPRESSED + BGZF_MAX + 64) {
         r->ccap = CHUNK_COMPRESSED + BGZF_MAX + 64;
         r->cbuf = xrealloc(r->cbuf, r->ccap);
     }
+    double tq = now_s();
     const size_t got = fread(r->cbuf + r->clen, 1, r->ccap - r->clen, r->f);
+    t_io += now_s() - tq;
     r->clen += got;
     if (r->clen == 0) {
-        r->eof = 1;
+        *peof = 1;
         return 0;
     }
     /* index the complete blocks */
-    static __thread struct blk *bl = NULL;
-    static __thread size_t bl_cap = 0;
+    struct blk *bl = r->blk;
     size_t nb = 0, off = 0, utot = 0;
     int damaged = 0;
     while (off + 18 <= r->clen) {
@@ -110,9 +136,9 @@ static size_t bgzf_load_chunk(aln_reader *r)
             damaged = 1;
             break;
         }
-        if (nb == bl_cap) {
-            bl_cap = bl_cap ? bl_cap * 2 : 4096;
-            bl = xrealloc(bl, sizeof *bl * bl_cap);
+        if (nb == r->blk_cap) {
+            r->blk_cap = r->blk_cap ? r->blk_cap * 2 : 4096;
+            bl = r->blk = xrealloc(r->blk, sizeof *bl * r->blk_cap);
         }
         bl[nb].coff = off;
         bl[nb].csize = bsize;
@@ -122,17 +148,19 @@ static size_t bgzf_load_chunk(aln_reader *r)
         utot += usize;
         off += bsize;
     }
-    if (r->ulen + utot + 64 > r->ucap) {
-        r->ucap = (r->ulen + utot) * 5 / 4 + BGZF_MAX + 64;
-        r->ubuf = xrealloc(r->ubuf, r->ucap);
+    if (at + utot + 64 > *pcap) {
+        *pcap = (at + utot) * 5 / 4 + BGZF_MAX + 64;
+        *pbuf = xrealloc(*pbuf, *pcap);
     }
+    tq = now_s();
     int bad = 0;
-    uint8_t *dst0 = r->ubuf + r->ulen;
-    const struct blk *blocks = bl;                             /* the thread-local pointer, shared with the workers */
+    uint8_t *dst0 = *pbuf + at;
+    const struct blk *blocks = bl;
     const uint8_t *cbase = r->cbuf;
 #pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
     for (long i = 0; i < (long)nb; i++)
         if (blocks[i].usize && inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
+    t_inflate += now_s() - tq;
     if (bad) {
         /* a block that does not inflate ends the stream there, like bgzf_read returning an error (bgzf.c:471-521) */
         size_t ok = 0;
@@ -143,13 +171,103 @@ static size_t bgzf_load_chunk(aln_reader *r)
         utot = ok;
         damaged = 1;
     }
-    r->ulen += utot;
     /* carry the incomplete tail block over */
     memmove(r->cbuf, r->cbuf + off, r->clen - off);
     r->clen -= off;
-    if (damaged || (got == 0 && nb == 0)) r->eof = 1;
-    if (got == 0 && r->clen > 0 && nb == 0) r->eof = 1;       /* truncated last block */
+    if (damaged || (got == 0 && nb == 0)) *peof = 1;
     return utot;
+}
+
+/* ---- read-ahead: while the caller hops over and parses one chunk, a loader thread reads and inflates the next one
+ * into the spare buffer, behind PF_HEAD bytes of room for the caller's unconsumed tail (a partial record). */
+#define PF_HEAD (4u << 20)
+static void *pf_main(void *arg)
+{
+    aln_reader *r = arg;
+    pthread_mutex_lock(&r->pf_mu);
+    for (;;) {
+        while (r->pf_state != 1 && !r->pf_stop) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
+        if (r->pf_stop) break;
+        pthread_mutex_unlock(&r->pf_mu);
+        int eof = 0;
+        const size_t n = bgzf_inflate_chunk(r, &r->nbuf, &r->ncap, PF_HEAD, &eof);
+        pthread_mutex_lock(&r->pf_mu);
+        r->nlen = n;
+        r->n_eof = eof;
+        r->pf_state = 2;
+        pthread_cond_broadcast(&r->pf_cv);
+    }
+    pthread_mutex_unlock(&r->pf_mu);
+    return NULL;
+}
+
+static void pf_request(aln_reader *r)
+{
+    pthread_mutex_lock(&r->pf_mu);
+    r->pf_state = 1;
+    pthread_cond_broadcast(&r->pf_cv);
+    pthread_mutex_unlock(&r->pf_mu);
+}
+
+static void pf_start(aln_reader *r)
+{
+    pthread_mutex_init(&r->pf_mu, NULL);
+    pthread_cond_init(&r->pf_cv, NULL);
+    r->pf_state = 0;
+    r->pf_stop = 0;
+    if (pthread_create(&r->pf_thread, NULL, pf_main, r) != 0) die("cannot start the BAM read-ahead thread");
+    r->pf_on = 1;
+    if (!r->eof) pf_request(r);
+}
+
+/* Makes more inflated bytes available behind the unconsumed ones. Returns the number of bytes added (0 at end of
+ * input). Synchronous while the header is read, from the read-ahead thread afterwards. */
+static size_t bgzf_load_chunk(aln_reader *r)
+{
+    if (r->eof) return 0;
+    if (!r->pf_on) {
+        /* keep what the record parser has not consumed */
+        if (r->upos) {
+            memmove(r->ubuf, r->ubuf + r->upos, r->ulen - r->upos);
+            r->ulen -= r->upos;
+            r->upos = 0;
+        }
+        int eof = 0;
+        const size_t n = bgzf_inflate_chunk(r, &r->ubuf, &r->ucap, r->ulen, &eof);
+        r->ulen += n;
+        if (eof) r->eof = 1;
+        return n;
+    }
+    pthread_mutex_lock(&r->pf_mu);
+    while (r->pf_state != 2) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
+    r->pf_state = 0;
+    pthread_mutex_unlock(&r->pf_mu);
+    const size_t tail = r->ulen - r->upos, n = r->nlen;
+    if (tail > PF_HEAD) {                                      /* a record of more than 4 MB: make room the slow way */
+        uint8_t *big = xmalloc(tail + n + 64);
+        memcpy(big, r->ubuf + r->upos, tail);
+        memcpy(big + tail, r->nbuf + PF_HEAD, n);
+        free(r->ubuf);
+        r->ubuf = big;
+        r->ucap = tail + n + 64;
+        r->upos = 0;
+        r->ulen = tail + n;
+    } else {
+        memcpy(r->nbuf + PF_HEAD - tail, r->ubuf + r->upos, tail);
+        uint8_t *tb = r->ubuf;
+        r->ubuf = r->nbuf;
+        r->nbuf = tb;
+        const size_t tc = r->ucap;
+        r->ucap = r->ncap;
+        r->ncap = tc;
+        r->upos = PF_HEAD - tail;
+        r->ulen = PF_HEAD + n;
+    }
+    if (r->n_eof)
+        r->eof = 1;
+    else
+        pf_request(r);
+    return n;
 }
 
 /* sequential read of n bytes (header parsing) */
@@ -270,7 +388,19 @@ aln_reader *aln_open(const char *path, int is_sam)
 void aln_close(aln_reader *r)
 {
     if (!r) return;
+    if (getenv("ITX_TIMING") && !r->is_sam)
+        fprintf(stderr, "[itx timing] BAM decode so far: file read %.3f s, inflate %.3f s, record hop %.3f s, parse %.3f s\n", t_io, t_inflate, t_hop, t_parse);
+    if (r->pf_on) {
+        pthread_mutex_lock(&r->pf_mu);
+        while (r->pf_state == 1) pthread_cond_wait(&r->pf_cv, &r->pf_mu);      /* let a chunk in flight land */
+        r->pf_stop = 1;
+        pthread_cond_broadcast(&r->pf_cv);
+        pthread_mutex_unlock(&r->pf_mu);
+        pthread_join(r->pf_thread, NULL);
+    }
     if (r->f) fclose(r->f);
+    free(r->nbuf);
+    free(r->blk);
     for (int i = 0; i < r->n_targets; i++) free(r->tname[i]);
     free(r->tname);
     names_free(&r->tnames);
@@ -376,10 +506,12 @@ static inline void bam_parse_one(const uint8_t *p, size_t n, itx_staging *st, al
 static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
     size_t n = 0;
+    if (!r->pf_on && !r->eof) pf_start(r);
     while (n < cap) {
         if (r->rec_next == r->n_rec) {
             /* locate the records of what is inflated; load more when none is complete */
             r->n_rec = r->rec_next = 0;
+            double th = now_s();
             for (;;) {
                 size_t p = r->upos;
                 while (p + 4 <= r->ulen) {
@@ -401,13 +533,18 @@ static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_sid
                     r->upos = p;                                  /* consumed up to here once these are parsed */
                     break;
                 }
-                if (bgzf_load_chunk(r) == 0 && r->eof) break;     /* end of input (a truncated tail record is dropped) */
+                const double tl = now_s();
+                const size_t more = bgzf_load_chunk(r);
+                th += now_s() - tl;                               /* the load is accounted as io / inflate */
+                if (more == 0 && r->eof) break;                   /* end of input (a truncated tail record is dropped) */
             }
+            t_hop += now_s() - th;
             if (r->n_rec == 0) break;
         }
         size_t m = r->n_rec - r->rec_next;
         if (m > cap - n) m = cap - n;
         const size_t *ro = r->rec_off + r->rec_next;
+        const double tp = now_s();
         int ap = 0, xa = 0;
 #pragma omp parallel for schedule(static) reduction(| : ap, xa)
         for (long i = 0; i < (long)m; i++) {
@@ -416,6 +553,7 @@ static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_sid
             ap |= a1;
             xa |= x1;
         }
+        t_parse += now_s() - tp;
         if (ap) *any_paired = 1;
         if (xa) *aux_xa = 1;
         r->rec_next += m;

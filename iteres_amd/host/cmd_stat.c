@@ -129,6 +129,7 @@ int main_stat(int argc, char **argv)
 
     const int timing = getenv("ITX_TIMING") != NULL;
     const double t_begin = now_s();
+    gpu_warmup_start();
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);
@@ -158,6 +159,7 @@ int main_stat(int argc, char **argv)
     res.cov = xcalloc(info.cov_len + 1, sizeof(uint32_t));
     res.cov_uniq = xcalloc(info.cov_len + 1, sizeof(uint32_t));
     if (itx_engine_finish(eng, &res) != ITX_OK) die("itx_engine_finish: %s", itx_last_error());
+    const double t_finished = now_s();
     cnt[11] -= hc.dup_unique;                     /* reads_nonredundant_unique: -R duplicates never reach it (generic.c:907-922) */
     cnt[12] = hc.diff_subfam;                     /* reads_diff_subfam (generic.c:978) */
     uint64_t *cov_off = xcalloc((size_t)rm.reps.n + 1, sizeof(uint64_t));
@@ -165,6 +167,7 @@ int main_stat(int argc, char **argv)
     write_wig_and_stat(&rm, &res, cov_off, outStat, o.keep_wig ? outWig : NULL, outFam, outCla, o.keep_wig ? outWigUniq : NULL, cnt[nindex],
                        cnt[nindex2]);
 
+    const double t_stats = now_s();
     /* stat.c:156-158: the two wigs as bigWig (written from the vectors, not by re-reading the text) */
     fprintf(stderr, "* Generating bigWig files\n");
     {
@@ -188,9 +191,12 @@ int main_stat(int argc, char **argv)
     fprintf(stderr, "* Preparing report file\n");
     write_report(outReport, cnt, o.mapq, "ALL");
 
-    if (timing)
+    if (timing) {
         fprintf(stderr, "[itx timing] load %.3f s, table+scan %.3f s, finish+write %.3f s\n", t_loaded - t_begin, t_streamed - t_loaded,
                 now_s() - t_streamed);
+        fprintf(stderr, "[itx timing] finish %.3f s, stat + wig files %.3f s, bigWig files + report %.3f s\n", t_finished - t_streamed,
+                t_stats - t_finished, now_s() - t_stats);
+    }
     itx_engine_destroy(eng);
     itx_table_destroy(tab);
     rmsk_free(&rm);

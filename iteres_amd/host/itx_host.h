@@ -119,6 +119,7 @@ char *filename_without_ext(const char *path);
 /* Runs the record loop (generic.c:700-1062 / 343-697) over one or more files through the engine.
  * progress_every: 100000 (stat, generic.c:760) or 10000 (filter, generic.c:397). want_qnames: per-locus read
  * names (filter -r): *locus_names[row] receives a comma-joined list in BAM order. */
+void gpu_warmup_start(void);      /* starts the HIP runtime on a helper thread; run_stream joins it */
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
                 unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names,
                 host_counts *hc);

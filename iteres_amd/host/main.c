@@ -3,6 +3,8 @@
  * outside this build's scope and say so. */
 #include "itx_host.h"
 
+#include <omp.h>
+#include <stdlib.h>
 #include <string.h>
 
 static int usage(void)
@@ -22,6 +24,14 @@ static int usage(void)
 int main(int argc, char *argv[])
 {
     if (argc < 2) return usage();
+    /* host threads (BGZF inflate, record parse, bigWig deflate): OMP_NUM_THREADS when given, else the processors this
+     * process may run on, capped — the decode saturates long before a big host's core count and idle OpenMP workers
+     * spinning on a shared box cost more than they give */
+    if (!getenv("OMP_NUM_THREADS")) {
+        int n = omp_get_num_procs();
+        if (n > 32) n = 32;
+        omp_set_num_threads(n > 0 ? n : 1);
+    }
     if (strcmp(argv[1], "stat") == 0) return main_stat(argc - 1, argv + 1);
     else if (strcmp(argv[1], "filter") == 0) return main_filter(argc - 1, argv + 1);
     else if (strcmp(argv[1], "cpgstat") == 0 || strcmp(argv[1], "cpgfilter") == 0) {

@@ -14,6 +14,34 @@
 
 #define BATCH_RECORDS (4u << 20)
 
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* The first HIP call costs a few hundred milliseconds of runtime start-up; a helper thread pays them while the main
+ * thread parses the rmsk file. */
+#include <pthread.h>
+static pthread_t warm_thread;
+static int warm_on;
+static void *warm_main(void *arg)
+{
+    (void)arg;
+    (void)itx_device_count();
+    return NULL;
+}
+void gpu_warmup_start(void)
+{
+    if (!warm_on && pthread_create(&warm_thread, NULL, warm_main, NULL) == 0) warm_on = 1;
+}
+static void gpu_warmup_join(void)
+{
+    if (warm_on) pthread_join(warm_thread, NULL);
+    warm_on = 0;
+}
+
 static void chk(int rc, const char *what)
 {
     if (rc != ITX_OK) die("%s: %s", what, itx_last_error());
@@ -82,6 +110,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
 {
     const int timing = getenv("ITX_TIMING") != NULL;
     struct timespec ts0, ts1;
+    gpu_warmup_join();
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     int ndev = itx_device_count();
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
@@ -196,29 +225,53 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             chk(itx_engine_set_tidmap(eng, &none, 1), "itx_engine_set_tidmap");
         }
         int s = 0, any_paired = 0, aux_xa = 0;
+        double t_wait = 0, t_read = 0, t_host = 0, t_submit = 0, tq;
         for (;;) {
             /* slot s: collect what its previous batch left behind, then refill */
+            tq = now_s();
             chk(itx_engine_wait_slot(eng, s), "itx_engine_wait_slot");
+            t_wait += now_s() - tq;
             if (pend[s]) {
                 if (want_qnames) collect_names(&hn, &st[s], &side[s], pend[s]);
                 side_release(&side[s], pend[s], want_qnames);
                 pend[s] = 0;
             }
+            aux_xa = 0;                                                        /* per batch */
+            tq = now_s();
             const size_t n = aln_read_batch(rd, &st[s], BATCH_RECORDS, any_side ? &side[s] : NULL, &any_paired, &aux_xa);
+            t_read += now_s() - tq;
             if (n == 0) break;
-            for (size_t i = 0; i < n; i++) {
-                /* generic.c:760-761 progress; generic.c:793-801 one warning per unknown chromosome */
-                if (++ends % progress_every == 0) fprintf(stderr, "\r* Processed read ends: %llu", ends);
-                const int32_t t = st[s].tid[i];
-                if (!(st[s].flag5[i] & 2) && t >= 0 && t < nt && t2c[t] == -1 && names_find(&warned, t2name[t]) < 0) {
-                    names_intern(&warned, t2name[t]);
-                    warnf("* Warning: read ends mapped to chromosome %s will be discarded as %s not existed in the chromosome size file",
-                          t2name[t], t2name[t]);
+            tq = now_s();
+            /* generic.c:760-761 progress; generic.c:793-801 one warning per unknown chromosome, in file order. Batches
+             * without a mapped record on an unknown chromosome (all of them, for most files) only print the progress marks. */
+            int unknown = 0;
+            {
+                const int32_t *tidv = st[s].tid;
+                const uint8_t *f5 = st[s].flag5;
+#pragma omp parallel for schedule(static) reduction(| : unknown)
+                for (long i = 0; i < (long)n; i++) {
+                    const int32_t t = tidv[i];
+                    if (!(f5[i] & 2) && t >= 0 && t < nt && t2c[t] == -1) unknown |= 1;
+                }
+            }
+            if (!unknown) {
+                for (unsigned long long m = (ends / progress_every + 1) * progress_every; m <= ends + n; m += progress_every)
+                    fprintf(stderr, "\r* Processed read ends: %llu", m);
+                ends += n;
+            } else {
+                for (size_t i = 0; i < n; i++) {
+                    if (++ends % progress_every == 0) fprintf(stderr, "\r* Processed read ends: %llu", ends);
+                    const int32_t t = st[s].tid[i];
+                    if (!(st[s].flag5[i] & 2) && t >= 0 && t < nt && t2c[t] == -1 && names_find(&warned, t2name[t]) < 0) {
+                        names_intern(&warned, t2name[t]);
+                        warnf("* Warning: read ends mapped to chromosome %s will be discarded as %s not existed in the chromosome size file",
+                              t2name[t], t2name[t]);
+                    }
                 }
             }
             /* ---- in file order: -R and the bed lines (generic.c:907-936) */
             int batch_xa = 0;
-            if (live) {
+            if (dups || bed_f || bed_uniq_f) {
                 for (size_t i = 0; i < n; i++) {
                     const int32_t t = st[s].tid[i];
                     const int32_t chrom = (t >= 0 && t < nt) ? t2c[t] : -1;
@@ -244,25 +297,46 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                         fprintf(bed_uniq_f, "%s\t%u\t%u\t%s\t%i\t%c\n", t2name[t], iv[i].start, iv[i].end, side[s].qname[i], (int)st[s].mapq[i],
                                 iv[i].strand);
                 }
+            } else if (veto_on && aux_xa) {
+                /* only the veto needs the intervals, and only of the records that carry XA: no order involved */
+                batch_xa = 1;
+#pragma omp parallel for schedule(static)
+                for (long i = 0; i < (long)n; i++) {
+                    live[i] = 0;
+                    if (!side[s].xa[i]) continue;
+                    const int32_t t = st[s].tid[i];
+                    const int32_t chrom = (t >= 0 && t < nt) ? t2c[t] : -1;
+                    live[i] = (uint8_t)host_derive(o, chrom, chrom >= 0 ? chr_sizes->value[chrom] : 0, st[s].flag5[i], st[s].pos[i],
+                                                   st[s].tmpend[i], st[s].mpos[i], st[s].isize[i], &iv[i]);
+                }
             }
             /* ---- the XA veto needs the chosen row first: classify the slot, look, mark, then count (generic.c:972-982) */
             if (veto_on && batch_xa) {
                 if (!xi) xi = xa_index_new(rm);
                 chk(itx_engine_classify_slot(eng, s, n, any_paired), "itx_engine_classify_slot");
                 chk(itx_engine_wait_slot(eng, s), "itx_engine_wait_slot");
-                for (size_t i = 0; i < n; i++) {
+                unsigned long long vetoed = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : vetoed)
+                for (long i = 0; i < (long)n; i++) {
                     if (!live[i] || !side[s].xa[i] || st[s].hit_row[i] < 0) continue;
                     const uint32_t rep = rm->rows[st[s].hit_row[i]].rep;
                     if (xa_veto(xi, rep, side[s].nm[i], side[s].xa[i], (int)(iv[i].end - iv[i].start))) {
                         st[s].flag5[i] |= ITX_F5_NOLOOKUP;
-                        if (hc) hc->diff_subfam++;
+                        vetoed++;
                     }
                 }
+                if (hc) hc->diff_subfam += vetoed;
             }
+            t_host += now_s() - tq;
+            tq = now_s();
             chk(itx_engine_submit_slot(eng, s, n, any_paired, want_qnames), "itx_engine_submit_slot");
+            t_submit += now_s() - tq;
             pend[s] = n;
             s ^= 1;
         }
+        if (timing)
+            fprintf(stderr, "[itx timing] stream of %s: decode %.3f s, host passes %.3f s, submit %.3f s, waiting for the device %.3f s\n", files[fi],
+                    t_read, t_host, t_submit, t_wait);
         /* drain both slots before the tid map of the next file replaces this one */
         for (int k = 0; k < 2; k++) {
             chk(itx_engine_wait_slot(eng, k), "itx_engine_wait_slot");

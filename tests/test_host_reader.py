@@ -23,8 +23,11 @@ def dump(tmp_path_factory):
     return exe
 
 
-def run_dump(exe, path, is_sam, batch=4096, threads=4):
-    pr = subprocess.run([exe, path, str(int(is_sam)), str(batch)], capture_output=True, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+def run_dump(exe, path, is_sam, batch=4096, threads=4, chunk=None):
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+    if chunk:
+        env["ITX_BGZF_CHUNK"] = str(chunk)          # compressed bytes per read-ahead step: small = many buffer swaps
+    pr = subprocess.run([exe, path, str(int(is_sam)), str(batch)], capture_output=True, text=True, env=env)
     assert pr.returncode == 0, pr.stderr
     hdr, recs, tail = [], [], None
     for line in pr.stdout.split("\n"):
@@ -72,12 +75,18 @@ def test_many_small_blocks_and_truncation(dump, tmp_path):
         hdr, recs, tail, _ = run_dump(dump, path, False, batch=9999, threads=threads)
         check(hdr, recs, header, rd)
         assert "xa=1" in tail
+    # the read-ahead thread with tiny steps: hundreds of buffer swaps, every one with a partial record carried over
+    for chunk, batch in ((3000, 9999), (50_000, 1234), (1, 4096)):
+        hdr, recs, tail, _ = run_dump(dump, path, False, batch=batch, threads=3, chunk=chunk)
+        check(hdr, recs, header, rd)
     # truncated in the middle of a block: a clean prefix of the records, no crash
     data = open(path, "rb").read()
     cut = str(tmp_path / "cut.bam")
     open(cut, "wb").write(data[: len(data) * 2 // 3 + 11])
     hdr, recs, tail, _ = run_dump(dump, cut, False, batch=4096)
     assert 0 < len(recs) < len(rd["tid"])
+    hdr2, recs2, _, _ = run_dump(dump, cut, False, batch=4096, chunk=20_000)
+    assert recs2 == recs
     for i in (0, len(recs) // 2, len(recs) - 1):
         assert int(recs[i][1]) == int(rd["pos"][i]) and recs[i][7] == rd["qname"][i]
     # not a BAM at all

@@ -334,9 +334,6 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             pend[s] = n;
             s ^= 1;
         }
-        if (timing)
-            fprintf(stderr, "[itx timing] stream of %s: decode %.3f s, host passes %.3f s, submit %.3f s, waiting for the device %.3f s\n", files[fi],
-                    t_read, t_host, t_submit, t_wait);
         /* drain both slots before the tid map of the next file replaces this one */
         for (int k = 0; k < 2; k++) {
             chk(itx_engine_wait_slot(eng, k), "itx_engine_wait_slot");
@@ -347,6 +344,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             pend[k] = 0;
         }
         fprintf(stderr, "\r* Processed read ends: %llu\n", ends);
+        if (timing)
+            fprintf(stderr, "[itx timing] stream of %s: decode %.3f s, host passes %.3f s, submit %.3f s, waiting for the device %.3f s\n", files[fi],
+                    t_read, t_host, t_submit, t_wait);
         for (int t = 0; t < nt; t++) free(t2name[t]);
         free(t2name);
         free(t2id);

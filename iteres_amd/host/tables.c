@@ -9,6 +9,7 @@
 #include <errno.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <omp.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -270,21 +271,59 @@ int64_t sizes_get(const sizes_t *s, const char *name, int64_t dflt)
         }                                                         \
     } while (0)
 
-void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_sizes, int filter_field, const char *filter_name,
-               rmsk_t *r)
+/* The rmsk file is parsed in pieces of whole lines, one per thread, each with the reference's row-by-row bookkeeping
+ * (generic.c:1578-1707) on its own tables; the pieces are then joined in file order, which gives every name the id it
+ * would have got from one pass (ids are first-appearance ranks, and the pieces are contiguous). */
+typedef struct {
+    rmsk_t r;
+    size_t cap_rows, cap_chr, cap_rep, cap_fam, cap_cla;
+    char *err;                 /* first fatal message of the piece, NULL when none */
+} rmsk_part;
+
+#define PART_DIE(...)                                   \
+    do {                                                \
+        if (asprintf(&pt->err, __VA_ARGS__) < 0) pt->err = NULL; \
+        return;                                         \
+    } while (0)
+
+static void rmsk_parse_piece(char *text, size_t lo, size_t hi, size_t flen, const char *path, const sizes_t *chr_sizes, const sizes_t *rep_sizes,
+                             int filter_field, const char *filter_name, rmsk_part *pt)
 {
-    lines_t l;
-    char *w[17];
-    int n;
-    memset(r, 0, sizeof *r);
+    rmsk_t *r = &pt->r;
+    size_t cap_rows = 0, cap_chr = 0, cap_rep = 0, cap_fam = 0, cap_cla = 0;
     names_init(&r->chroms);
     names_init(&r->reps);
     names_init(&r->fams);
     names_init(&r->clas);
-    size_t cap_rows = 0, cap_chr = 0, cap_rep = 0, cap_fam = 0, cap_cla = 0;
-    lines_open(&l, path);
-    while ((n = lines_next_words(&l, w, 17)) != 0) {
-        if (n < 17) die("Expecting %d words line %d of %s got %d", 17, l.line_ix, path, n);
+    /* lo and hi are line starts (rmsk_load cuts the file before any piece puts its NULs into the text) */
+    size_t p = lo;
+    while (p < hi) {
+        char *line = text + p;
+        const char *nl = memchr(line, '\n', flen - p);
+        const size_t next = nl ? (size_t)(nl - text) + 1 : flen;
+        char *end = text + (nl ? (size_t)(nl - text) : flen);
+        const size_t line_off = p;
+        p = next;
+        if (*line == '#') continue;
+        /* chopByWhite into at most 17 words (cuskent/linefile.c:855-870, common.c:1915-1953) */
+        char *w[17];
+        int n = 0;
+        for (char *c = line;;) {
+            if (n >= 17) break;
+            while (c < end && isspace((unsigned char)*c)) ++c;
+            if (c >= end || *c == 0) break;
+            w[n++] = c;
+            while (c < end && *c && !isspace((unsigned char)*c)) ++c;
+            if (c >= end || *c == 0) break;
+            *c++ = 0;
+        }
+        if (end < text + flen) *end = 0;
+        if (n == 0) continue;
+        if (n < 17) {
+            int line_ix = 1;
+            for (size_t k = 0; k < line_off; k++) line_ix += text[k] == '\n';
+            PART_DIE("Expecting %d words line %d of %s got %d", 17, line_ix, path, n);
+        }
         if (filter_field != 0 && strcmp(filter_name, w[filter_field]) != 0) continue;      /* generic.c:1588-1591 */
         r->repeat_num++;
         /* generic.c:1594-1607: (unsigned int)strtol(..., 0) */
@@ -300,7 +339,7 @@ void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_si
         if (ci < 0) {
             const int size = (int)sizes_get(chr_sizes, w[5], 0);
             if (size == 0) continue;                                                        /* freermsk + continue */
-            if (size < 0) die("bad range %d,%d in binKeeperNew", 0, size);                  /* cuskent/binRange.c:145-146 */
+            if (size < 0) PART_DIE("bad range %d,%d in binKeeperNew", 0, size);                  /* cuskent/binRange.c:145-146 */
             ci = names_intern(&r->chroms, w[5]);
             GROW(r->chrom_size, (size_t)ci, cap_chr, int64_t);
             r->chrom_size[ci] = size;
@@ -308,7 +347,7 @@ void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_si
         /* binKeeperAdd's range check (cuskent/binRange.c:176-178); itx_table_create repeats it for the whole table */
         {
             const int s = (int)row.start, e = (int)row.end, mx = (int)r->chrom_size[ci];
-            if (s < 0 || e > mx || s > e) die("(%d %d) out of range (%d %d) in binKeeperAdd", s, e, 0, mx);
+            if (s < 0 || e > mx || s > e) PART_DIE("(%d %d) out of range (%d %d) in binKeeperAdd", s, e, 0, mx);
         }
         row.chrom = (int32_t)names_find(&chr_sizes->names, w[5]);      /* the engine indexes chromosomes as the size file does */
         row.rep = row.fam = row.cla = 0;
@@ -372,7 +411,136 @@ void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_si
         r->row_chrom_name[r->n_rows] = (uint32_t)ci;
         r->n_rows++;
     }
+    pt->cap_rows = cap_rows;
+    (void)cap_chr; (void)cap_rep; (void)cap_fam; (void)cap_cla;
+}
+
+void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_sizes, int filter_field, const char *filter_name,
+               rmsk_t *r)
+{
+    lines_t l;
+    memset(r, 0, sizeof *r);
+    /* the whole file in memory (also when it comes through a decompressor pipe) */
+    lines_open(&l, path);
+    size_t flen = 0, fcap = 1u << 24;
+    char *text = xmalloc(fcap + 1);
+    for (;;) {
+        const size_t got = fread(text + flen, 1, fcap - flen, l.f);
+        flen += got;
+        if (got == 0) break;
+        if (flen == fcap) {
+            fcap *= 2;
+            text = xrealloc(text, fcap + 1);
+        }
+    }
+    text[flen] = 0;
     lines_close(&l);
+    int T = omp_get_max_threads();
+    if (T < 1) T = 1;
+    if ((size_t)T > flen / 65536 + 1) T = (int)(flen / 65536 + 1);
+    rmsk_part *parts = xcalloc((size_t)T, sizeof *parts);
+    size_t *cut = xcalloc((size_t)T + 1, sizeof *cut);            /* piece t = lines starting in [cut[t], cut[t+1]) */
+    for (int t = 1; t < T; t++) {
+        const size_t at = flen * (size_t)t / (size_t)T;            /* a line belongs to the piece its first byte lies in */
+        const char *nl = memchr(text + at - 1, '\n', flen - (at - 1));
+        cut[t] = nl ? (size_t)(nl - text) + 1 : flen;
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    cut[T] = flen;
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++)
+        rmsk_parse_piece(text, cut[t], cut[t + 1], flen, path, chr_sizes, rep_sizes, filter_field, filter_name, &parts[t]);
+    free(cut);
+    for (int t = 0; t < T; t++)
+        if (parts[t].err) die("%s", parts[t].err);             /* the first one in file order, like a single pass */
+    /* ---- join in file order */
+    names_init(&r->chroms);
+    names_init(&r->reps);
+    names_init(&r->fams);
+    names_init(&r->clas);
+    size_t total_rows = 0;
+    for (int t = 0; t < T; t++) total_rows += parts[t].r.n_rows;
+    r->rows = xmalloc(sizeof(itx_row) * (total_rows ? total_rows : 1));
+    r->row_chrom_name = xmalloc(sizeof(uint32_t) * (total_rows ? total_rows : 1));
+    size_t cap_chr = 0, cap_rep = 0, cap_fam = 0, cap_cla = 0;
+    for (int t = 0; t < T; t++) {
+        rmsk_t *q = &parts[t].r;
+        r->repeat_num += q->repeat_num;
+        uint32_t *mc = xmalloc(sizeof(uint32_t) * (q->chroms.n + 1)), *mf = xmalloc(sizeof(uint32_t) * (q->fams.n + 1));
+        uint32_t *ml = xmalloc(sizeof(uint32_t) * (q->clas.n + 1)), *mr = xmalloc(sizeof(uint32_t) * (q->reps.n + 1));
+        for (uint32_t i = 0; i < q->chroms.n; i++) {
+            const uint32_t g = names_intern(&r->chroms, q->chroms.name[i]);
+            GROW(r->chrom_size, (size_t)g, cap_chr, int64_t);
+            r->chrom_size[g] = q->chrom_size[i];
+            mc[i] = g;
+        }
+        for (uint32_t i = 0; i < q->clas.n; i++) {
+            const uint32_t before = r->clas.n, g = names_intern(&r->clas, q->clas.name[i]);
+            if (g == before) {
+                if (g >= cap_cla) {
+                    cap_cla = cap_cla ? cap_cla * 2 : 64;
+                    r->cla_genome = xrealloc(r->cla_genome, sizeof(uint64_t) * cap_cla);
+                    r->cla_total = xrealloc(r->cla_total, sizeof(uint64_t) * cap_cla);
+                }
+                r->cla_genome[g] = 0;
+                r->cla_total[g] = 0;
+            }
+            r->cla_genome[g] += q->cla_genome[i];
+            r->cla_total[g] += q->cla_total[i];
+            ml[i] = g;
+        }
+        for (uint32_t i = 0; i < q->fams.n; i++) {
+            const uint32_t before = r->fams.n, g = names_intern(&r->fams, q->fams.name[i]);
+            if (g == before) {
+                if (g >= cap_fam) {
+                    cap_fam = cap_fam ? cap_fam * 2 : 256;
+                    r->fam_cla = xrealloc(r->fam_cla, sizeof(uint32_t) * cap_fam);
+                    r->fam_genome = xrealloc(r->fam_genome, sizeof(uint64_t) * cap_fam);
+                    r->fam_total = xrealloc(r->fam_total, sizeof(uint64_t) * cap_fam);
+                }
+                r->fam_cla[g] = ml[q->fam_cla[i]];              /* class of the family's first row in the file */
+                r->fam_genome[g] = 0;
+                r->fam_total[g] = 0;
+            }
+            r->fam_genome[g] += q->fam_genome[i];
+            r->fam_total[g] += q->fam_total[i];
+            mf[i] = g;
+        }
+        for (uint32_t i = 0; i < q->reps.n; i++) {
+            const uint32_t before = r->reps.n, g = names_intern(&r->reps, q->reps.name[i]);
+            if (g == before) {
+                if (g >= cap_rep) {
+                    cap_rep = cap_rep ? cap_rep * 2 : 1024;
+                    r->rep_len = xrealloc(r->rep_len, sizeof(uint32_t) * cap_rep);
+                    r->rep_fam = xrealloc(r->rep_fam, sizeof(uint32_t) * cap_rep);
+                    r->rep_cla = xrealloc(r->rep_cla, sizeof(uint32_t) * cap_rep);
+                    r->rep_genome = xrealloc(r->rep_genome, sizeof(uint64_t) * cap_rep);
+                    r->rep_total = xrealloc(r->rep_total, sizeof(uint64_t) * cap_rep);
+                }
+                r->rep_len[g] = q->rep_len[i];
+                r->rep_fam[g] = mf[q->rep_fam[i]];              /* family / class of the name's first row in the file */
+                r->rep_cla[g] = ml[q->rep_cla[i]];
+                r->rep_genome[g] = 0;
+                r->rep_total[g] = 0;
+            }
+            r->rep_genome[g] += q->rep_genome[i];
+            r->rep_total[g] += q->rep_total[i];
+            mr[i] = g;
+        }
+        for (size_t i = 0; i < q->n_rows; i++) {
+            itx_row row = q->rows[i];
+            row.rep = mr[row.rep];
+            row.fam = mf[row.fam];
+            row.cla = ml[row.cla];
+            r->rows[r->n_rows] = row;
+            r->row_chrom_name[r->n_rows] = mc[q->row_chrom_name[i]];
+            r->n_rows++;
+        }
+        free(mc); free(mf); free(ml); free(mr);
+        rmsk_free(q);
+    }
+    free(parts);
+    free(text);
 }
 
 void rmsk_free(rmsk_t *r)

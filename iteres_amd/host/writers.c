@@ -40,6 +40,20 @@ void write_report(const char *path, const uint64_t *cnt, unsigned mapQ, const ch
     fclose(f);
 }
 
+/* "%u\n" */
+static inline char *put_u32_line(char *p, uint32_t v)
+{
+    char t[10];
+    int n = 0;
+    do {
+        t[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = t[--n];
+    *p++ = '\n';
+    return p;
+}
+
 void write_wig_and_stat(const rmsk_t *rm, const itx_result *res, const uint64_t *cov_off, const char *f_stat, const char *f_wig,
                         const char *f_fam, const char *f_cla, const char *f_wig_uniq, unsigned long long reads_num,
                         unsigned long long reads_num_unique)
@@ -59,13 +73,35 @@ void write_wig_and_stat(const rmsk_t *rm, const itx_result *res, const uint64_t 
         fprintf(f1, "%s\t%s\t%s\t%u\t%llu\t%llu\t%llu\t%llu\t%.3f\t%.3f\t%.3f\t%.3f\n", rm->reps.name[r], rm->fams.name[rm->rep_fam[r]],
                 rm->clas.name[rm->rep_cla[r]], rm->rep_len[r], rc, ru, tl, (unsigned long long)rm->rep_genome[r],
                 cal_rpkm(rc, tl, reads_num), cal_rpm(rc, reads_num), cal_rpkm(ru, tl, reads_num_unique), cal_rpm(ru, reads_num_unique));
-        if (rm->rep_len[r] != 0 && f2 && f5) {
-            fprintf(f2, "fixedStep chrom=%s start=1 step=1 span=1\n", rm->reps.name[r]);
-            fprintf(f5, "fixedStep chrom=%s start=1 step=1 span=1\n", rm->reps.name[r]);
-            const uint32_t *a = res->cov + cov_off[r], *b = res->cov_uniq + cov_off[r];
-            for (uint32_t m = 0; m < rm->rep_len[r]; m++) {
-                fprintf(f2, "%u\n", a[m]);
-                fprintf(f5, "%u\n", b[m]);
+    }
+    /* the two wigs (generic.c:83-90), same order: one "%u\n" per base. The blocks are formatted in parallel, a group of
+     * names at a time, and written in order. */
+    if (f2 && f5) {
+        enum { GROUP = 512 };
+        char *buf[2][GROUP];
+        size_t len[2][GROUP];
+        for (uint32_t k0 = 0; k0 < S; k0 += GROUP) {
+            const uint32_t k1 = k0 + GROUP < S ? k0 + GROUP : S;
+#pragma omp parallel for schedule(dynamic, 4)
+            for (long k = (long)k0; k < (long)k1; k++) {
+                const uint32_t r = order[k];
+                for (int w = 0; w < 2; w++) {
+                    buf[w][k - k0] = NULL;
+                    len[w][k - k0] = 0;
+                    if (rm->rep_len[r] == 0) continue;
+                    const uint32_t *v = (w ? res->cov_uniq : res->cov) + cov_off[r];
+                    char *b = xmalloc(64 + strlen(rm->reps.name[r]) + 11 * (size_t)rm->rep_len[r]);
+                    char *p = b + sprintf(b, "fixedStep chrom=%s start=1 step=1 span=1\n", rm->reps.name[r]);
+                    for (uint32_t m = 0; m < rm->rep_len[r]; m++) p = put_u32_line(p, v[m]);
+                    buf[w][k - k0] = b;
+                    len[w][k - k0] = (size_t)(p - b);
+                }
+            }
+            for (uint32_t k = k0; k < k1; k++) {
+                if (buf[0][k - k0]) fwrite(buf[0][k - k0], 1, len[0][k - k0], f2);
+                if (buf[1][k - k0]) fwrite(buf[1][k - k0], 1, len[1][k - k0], f5);
+                free(buf[0][k - k0]);
+                free(buf[1][k - k0]);
             }
         }
     }

@@ -45,7 +45,7 @@ struct ItxPartWork {
     uint32_t max_items;
     uint2 *keys0;              // [2*cap] 8-byte keys as emitted, per workgroup region
     uint32_t *keys1;           // [2*cap] 4-byte keys, partitioned
-    uint32_t *blk_cnt;         // [max_blocks] keys emitted by each workgroup
+    uint32_t *blk_cnt;         // [max_blocks][4] keys emitted by each wave of each workgroup (into its quarter of the region)
     uint32_t *subcur;          // [n_part*8] sub-totals, then (after k_plan) bases
     uint32_t *offm;            // [max_blocks][n_part] offset of each region inside (partition, sub)
     uint4    *items;           // [max_items] (partition, begin, end, exclusive)
@@ -74,7 +74,7 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
     size_t off = 0;
     const size_t o_k0 = off; off = al256(off + 2 * kcap);
     const size_t o_k1 = off; off = al256(off + kcap);
-    const size_t o_bc = off; off = al256(off + (size_t)w->max_blocks * 4);
+    const size_t o_bc = off; off = al256(off + (size_t)w->max_blocks * 4 * 4);
     const size_t o_sc = off; off = al256(off + ((size_t)w->n_part * ITX_SUB + 1) * 4);
     const size_t o_om = off; off = al256(off + (size_t)w->max_blocks * w->n_part * 4);
     const size_t o_it = off; off = al256(off + (size_t)w->max_items * 16);
@@ -165,29 +165,31 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0,
     const uint32_t *row = offm + (size_t)blockIdx.x * n_part;
     for (uint32_t k = threadIdx.x; k < n_part; k += PB) s_cur[k] = subcur[k * ITX_SUB + sub] + row[k];
     __syncthreads();
-    const uint32_t total = blk_cnt[blockIdx.x];
-    const uint2 *in = keys0 + 2 * (size_t)blockIdx.x * span;
     const uint32_t lane = threadIdx.x & 63u;
     // 8 rounds of 256 keys per iteration: the loads of all eight are in flight before the first is used
     // (one round after the other leaves the kernel waiting on one global load per 256 keys per workgroup)
     constexpr int U = 8;
-    for (uint32_t r0 = 0; r0 < total; r0 += U * PB) {
-        uint2 key[U];
+    for (uint32_t q = 0; q < 4; q++) {                         // the four waves of the emitting workgroup filled a quarter each
+        const uint32_t total = blk_cnt[4 * blockIdx.x + q];
+        const uint2 *in = keys0 + 2 * (size_t)blockIdx.x * span + (size_t)q * (span / 2);
+        for (uint32_t r0 = 0; r0 < total; r0 += U * PB) {
+            uint2 key[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t idx = r0 + u * PB + threadIdx.x;
-            key[u] = idx < total ? in[idx] : make_uint2(0, 0xffffffffu);
-        }
+            for (int u = 0; u < U; u++) {
+                const uint32_t idx = r0 + u * PB + threadIdx.x;
+                key[u] = idx < total ? in[idx] : make_uint2(0, 0xffffffffu);
+            }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bool has = key[u].y != 0xffffffffu;
-            const uint32_t p = has ? key[u].y >> ITX_LOGW : 0xffffffffu;
-            uint32_t len, leader;
-            const bool st = wave_run(p, has, lane, &len, &leader);
-            uint32_t base = 0;
-            if (st) base = atomicAdd(&s_cur[p], len);             // one returning LDS add per run
-            base = (uint32_t)__shfl((int32_t)base, (int)leader, 64);
-            if (has) keys1[base + (lane - leader)] = ((key[u].y & (ITX_W - 1)) << 16) | (key[u].x & 0xffffu);
+            for (int u = 0; u < U; u++) {
+                const bool has = key[u].y != 0xffffffffu;
+                const uint32_t p = has ? key[u].y >> ITX_LOGW : 0xffffffffu;
+                uint32_t len, leader;
+                const bool st = wave_run(p, has, lane, &len, &leader);
+                uint32_t base = 0;
+                if (st) base = atomicAdd(&s_cur[p], len);             // one returning LDS add per run
+                base = (uint32_t)__shfl((int32_t)base, (int)leader, 64);
+                if (has) keys1[base + (lane - leader)] = ((key[u].y & (ITX_W - 1)) << 16) | (key[u].x & 0xffffu);
+            }
         }
     }
 }

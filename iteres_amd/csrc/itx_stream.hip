@@ -25,7 +25,10 @@
 #ifndef ITX_LB
 #define ITX_LB ITX_STREAM_LB
 #endif
-#define RPL 4
+#ifndef ITX_RPL
+#define ITX_RPL 4          // records per lane and tile: 4 (16-byte loads) or 2 (8-byte loads, half the per-wave state)
+#endif
+#define RPL ITX_RPL
 #define WTILE (64 * RPL)
 
 // Everything generic.c:748-922 decides from a record's flag bits alone, tabulated once per workgroup.
@@ -130,16 +133,6 @@ __device__ __forceinline__ void classify_global(const ItxDevTable &T, const ItxR
     }
 }
 
-// Sixteen bytes of keys stored at any 4-byte boundary of the key stream with one instruction. The hardware takes unaligned
-// 16-byte global stores (the driver runs gfx9 compute queues in unaligned mode); the compiler, told only "aligned 4",
-// splits them into four, so the instruction is written out.
-typedef uint32_t itx_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_key4(uint32_t *dst, const uint4 &k)
-{
-    const itx_u32x4 v = {k.x, k.y, k.z, k.w};
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");   // nop: store-data hazard
-}
-
 template <int WHAT>
 __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunParams P, ItxDevBatch B, size_t n, size_t span,
                                                int32_t *__restrict__ d_hit_row, uint64_t *__restrict__ u64,
@@ -150,7 +143,6 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     __shared__ uint4 s_win[SB / 64][2 * (ITX_WIN + 1)];
     __shared__ uint32_t s_lut[1024];                           // entries 512.. are zero: records past the end carry fl = 512
     __shared__ uint32_t s_cnt[16];
-    __shared__ uint32_t s_cursor;
     extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
@@ -160,7 +152,6 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     s_lut[512 + threadIdx.x] = 0;
     s_lut[768 + threadIdx.x] = 0;
     if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_cursor = 0;
     if (lane == 0) {
         win[0] = make_uint4(0x3fffffffu, 0xc0000000u, 0x80000000u, 0xffffffffu);      // s, e, pbelow, rank
         win[1] = make_uint4(0, 0, 0, 0);
@@ -171,7 +162,8 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     const size_t begin = (size_t)blockIdx.x * span;
     size_t end = begin + span;
     if (end > n) end = n;
-    uint2 *out = keys0 ? keys0 + 2 * begin : nullptr;       // at most two keys per record
+    uint2 *w_out = keys0 ? keys0 + 2 * begin + (size_t)w * (span / 2) : nullptr;    // the wave's quarter: at most two keys per record
+    uint32_t w_keys = 0;
     const bool have_pe = B.isize != nullptr;
 
     // wave-uniform cache of the current reference's ItxTidRec
@@ -194,9 +186,12 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         const bool full = tb + WTILE <= end;                                    // wave-uniform
         ItxRaw raw[RPL];
         bool ex[RPL];
-        int32_t isz[RPL] = {0, 0, 0, 0}, mps[RPL] = {0, 0, 0, 0};
+        int32_t isz[RPL], mps[RPL];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) isz[j] = mps[j] = 0;
         bool tile_pe = have_pe;                                                 // wave-uniform: mate fields were read
         if (full) {
+#if RPL == 4
             const int4 t4 = *reinterpret_cast<const int4 *>(B.tid + r0);
             const int4 p4 = *reinterpret_cast<const int4 *>(B.pos + r0);
             const int4 e4 = *reinterpret_cast<const int4 *>(B.tmpend + r0);
@@ -206,14 +201,32 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             raw[1] = {t4.y, p4.y, e4.y, (mq >> 8) & 0xffu, (f4 >> 8) & 0x3fu};
             raw[2] = {t4.z, p4.z, e4.z, (mq >> 16) & 0xffu, (f4 >> 16) & 0x3fu};
             raw[3] = {t4.w, p4.w, e4.w, mq >> 24, (f4 >> 24) & 0x3fu};
+            const uint32_t paired_mask = 0x01010101u;
+#else
+            const int2 t4 = *reinterpret_cast<const int2 *>(B.tid + r0);
+            const int2 p4 = *reinterpret_cast<const int2 *>(B.pos + r0);
+            const int2 e4 = *reinterpret_cast<const int2 *>(B.tmpend + r0);
+            const uint32_t mq = *reinterpret_cast<const uint16_t *>(B.mapq + r0);
+            const uint32_t f4 = *reinterpret_cast<const uint16_t *>(B.flag5 + r0);
+            raw[0] = {t4.x, p4.x, e4.x, mq & 0xffu, f4 & 0x3fu};
+            raw[1] = {t4.y, p4.y, e4.y, (mq >> 8) & 0xffu, (f4 >> 8) & 0x3fu};
+            const uint32_t paired_mask = 0x0101u;
+#endif
 #pragma unroll
             for (int j = 0; j < RPL; j++) ex[j] = true;
-            tile_pe = have_pe && __ballot(f4 & 0x01010101u) != 0ull;            // some record of the tile is paired
+            tile_pe = have_pe && __ballot(f4 & paired_mask) != 0ull;            // some record of the tile is paired
             if (tile_pe) {
+#if RPL == 4
                 const int4 i4 = *reinterpret_cast<const int4 *>(B.isize + r0);
                 const int4 m4 = *reinterpret_cast<const int4 *>(B.mpos + r0);
                 isz[0] = i4.x; isz[1] = i4.y; isz[2] = i4.z; isz[3] = i4.w;
                 mps[0] = m4.x; mps[1] = m4.y; mps[2] = m4.z; mps[3] = m4.w;
+#else
+                const int2 i4 = *reinterpret_cast<const int2 *>(B.isize + r0);
+                const int2 m4 = *reinterpret_cast<const int2 *>(B.mpos + r0);
+                isz[0] = i4.x; isz[1] = i4.y;
+                mps[0] = m4.x; mps[1] = m4.y;
+#endif
             }
         } else {
 #pragma unroll
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 }
             }
         }
-        ITX_ABLATE_AT(1, raw[0].tid + raw[1].pos + raw[2].tmpend + raw[3].mapq + raw[3].fl)
+        ITX_ABLATE_AT(1, raw[0].tid + raw[1].pos + raw[0].tmpend + raw[1].mapq + raw[1].fl)
         // ---- per-reference record: wave-uniform when every record of the tile shares one tid
         bool same = true;
 #pragma unroll
@@ -258,9 +271,15 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         int32_t qs[RPL], qe[RPL];                  // for every record that goes on: also the reference's start / end
         bool q[RPL], uq[RPL];
         bool anyq = false, odd = !uniform;
-        int32_t hit[RPL] = {-1, -1, -1, -1};
-        uint32_t sA[RPL] = {0, 0, 0, 0}, sB[RPL] = {0, 0, 0, 0};  // slots of the start / end marks of the chosen row's consensus range
-        bool hB[RPL] = {false, false, false, false};              // the read adds coverage (else: one start in the unit's extra slot)
+        int32_t hit[RPL];
+        uint32_t sA[RPL], sB[RPL];                 // slots of the start / end marks of the chosen row's consensus range
+        bool hB[RPL];                              // the read adds coverage (else: one start in the unit's extra slot)
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+            hit[j] = -1;
+            sA[j] = sB[j] = 0;
+            hB[j] = false;
+        }
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
             uint32_t st, en;
@@ -287,7 +306,9 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         }
         // ---- cnt[0..7] (generic.c:1048-1055)
         {
-            const uint32_t n4 = lut[0] + lut[1] + lut[2] + lut[3];                      // 3-bit fields, each <= 4
+            uint32_t n4 = 0;                                                            // 3-bit fields, each <= RPL
+#pragma unroll
+            for (int j = 0; j < RPL; j++) n4 += lut[j];
             accA += n4 & 0x1c71c7u;
             accB += (n4 >> 3) & 0x1c71c7u;
             if (++tiles == 15) {                                                        // 15 * 4 < 64
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 accA = accB = tiles = 0;
             }
         }
-        ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + (uint32_t)qs[2] + (uint32_t)qe[3] + accA + accB)
+        ITX_ABLATE_AT(2, (uint32_t)qs[0] + (uint32_t)qe[1] + accA + accB)
 
         // ---- classify: every record left is on the cached reference
         if (__ballot(anyq)) {
@@ -427,7 +448,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                     if (q[j]) classify_global(T, P, cur0.z, cur_bb, qs[j], qe[j], (uint32_t)qs[j], (uint32_t)qe[j], hit[j], sA[j], sB[j], hB[j]);
             }
         }
-        ITX_ABLATE_AT(4, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]))
+        ITX_ABLATE_AT(4, (uint32_t)(hit[0] + hit[1]))
 
         // ---- hits (generic.c:1030-1032), per wave
         unsigned long long mA[RPL];
@@ -437,7 +458,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             n_hit += (uint32_t)__popcll(mA[j]);
             n_hitu += (uint32_t)__popcll(mA[j] & __ballot(uq[j]));
         }
-        ITX_ABLATE_AT(5, (uint32_t)(hit[0] + hit[1] + hit[2] + hit[3]) + n_hit)
+        ITX_ABLATE_AT(5, (uint32_t)(hit[0] + hit[1]) + n_hit)
 
         // ---- chosen rows back to the caller (row ids as passed to itx_table_create)
         if (d_hit_row) {
@@ -445,7 +466,11 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
 #pragma unroll
             for (int j = 0; j < RPL; j++) h[j] = hit[j] >= 0 ? T.orig[hit[j]] : -1;
             if (full) {
+#if RPL == 4
                 *reinterpret_cast<int4 *>(d_hit_row + r0) = make_int4(h[0], h[1], h[2], h[3]);
+#else
+                *reinterpret_cast<int2 *>(d_hit_row + r0) = make_int2(h[0], h[1]);
+#endif
             } else {
 #pragma unroll
                 for (int j = 0; j < RPL; j++)
@@ -478,10 +503,10 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             //   type 0: a start mark at slot and an end mark at slot + len (both inside one partition, len < 2^13)
             //   type 1: a start mark only (the read adds no coverage, or its end mark lies in another partition)
             //   type 2: an end mark only (the other half of such a read)
-            // The tile's keys leave in RECORD order (neighbouring records mostly hit the same row, so the partition
-            // path downstream sees long runs of one partition): every lane drops its keys behind those of the lanes
-            // below it in the wave's window — idle at this point — and the wave copies them out 16 bytes per lane.
-            uint2 *stage = reinterpret_cast<uint2 *>(win + 2);
+            // The keys leave in RECORD order (neighbouring records mostly hit the same row, so the partition path
+            // downstream sees long runs of one partition): every wave fills its own quarter of the workgroup's region
+            // front to back, a lane's keys right behind those of the lanes below it (DPP prefix sum) — 8-byte stores
+            // that together cover one contiguous stretch per tile. No cursor is shared, nothing is waited for.
             bool two[RPL];
             uint32_t c = 0;
 #pragma unroll
@@ -496,36 +521,22 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             ITX_DPP_STEP(uadd32, inc, 0, 0x118, 0xf);
             ITX_DPP_STEP(uadd32, inc, 0, 0x142, 0xa);
             ITX_DPP_STEP(uadd32, inc, 0, 0x143, 0xc);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int32_t)inc, 63);
-            if (total) {                                                         // wave-uniform
-                uint32_t at = inc - c;
+            uint32_t at = w_keys + inc - c;
+            w_keys += (uint32_t)__builtin_amdgcn_readlane((int32_t)inc, 63);     // wave-uniform
 #pragma unroll
-                for (int j = 0; j < RPL; j++) {
-                    const uint32_t u = uq[j] ? 4u : 0u;
-                    const uint32_t lo = (hB[j] && !two[j]) ? (((sB[j] - sA[j]) << 3) | u) : (1u | u);
-                    if (hit[j] >= 0) stage[at] = make_uint2(lo, sA[j]);
-                    at += hit[j] >= 0 ? 1u : 0u;
-                    if (two[j]) stage[at] = make_uint2(2u | u, sB[j]);
-                    at += two[j] ? 1u : 0u;
+            for (int j = 0; j < RPL; j++) {
+                const uint32_t u = uq[j] ? 4u : 0u;
+                const uint32_t lo = (hB[j] && !two[j]) ? (((sB[j] - sA[j]) << 3) | u) : (1u | u);
+                if (hit[j] >= 0) {
+                    w_out[at] = make_uint2(lo, sA[j]);
+                    atomicAdd(&s_pc[sA[j] >> E.log_w], 1u);                      // keys per partition of this workgroup's region
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&s_cursor, total);               // the workgroup's region cursor (LDS)
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)base);
-                for (uint32_t i = 2 * lane; i < total; i += 2 * 64) {
-                    const uint4 k2 = *reinterpret_cast<const uint4 *>(stage + i);        // two keys
-                    uint2 *dst = out + base + i;
-                    if (total - i >= 2) {
-                        store_key4(reinterpret_cast<uint32_t *>(dst), k2);
-                        atomicAdd(&s_pc[k2.w >> E.log_w], 1u);
-                    } else {
-                        dst[0] = make_uint2(k2.x, k2.y);
-                    }
-                    atomicAdd(&s_pc[k2.y >> E.log_w], 1u);                       // keys per partition of this workgroup's region
+                at += hit[j] >= 0 ? 1u : 0u;
+                if (two[j]) {
+                    w_out[at] = make_uint2(2u | u, sB[j]);
+                    atomicAdd(&s_pc[sB[j] >> E.log_w], 1u);
                 }
-                __builtin_amdgcn_wave_barrier();                                 // the window is rewritten next tile
+                at += two[j] ? 1u : 0u;
             }
         }
     }
@@ -553,7 +564,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     if (WHAT != ITX_DO_CLASSIFY && threadIdx.x < 16 && s_cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&u64[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
     if (WHAT == ITX_DO_EMIT) {
-        if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cursor;
+        if (lane == 0) blk_cnt[4 * blockIdx.x + w] = w_keys;
         // reserve this region's places: ONE add per touched partition, on one of 8 sub-cursors (workgroup id mod 8 —
         // workgroups are dealt round-robin over the 8 XCDs, so no address sees more than n_blocks/8 adds). The
         // offsets are kept as this region's row of the offset matrix for k_scatter.
@@ -588,7 +599,7 @@ int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, con
         itx_set_error("record arrays must be 16-byte aligned (tid/pos/tmpend/mpos/isize/hit_row) and 4-byte aligned (mapq/flag5)");
         return ITX_E_ARG;
     }
-    if (span % ITX_STREAM_TILE || span > (size_t)16000 * ITX_STREAM_TILE) {         // 16-bit per-lane counters: <= 16383 tiles per wave
+    if (span % ITX_STREAM_TILE || span > (size_t)16000 * ITX_STREAM_TILE) {         // 16-bit per-lane counters: <= 65535 / RPL tiles per wave
         itx_set_error("internal: span %zu is not a multiple of %u or too long", span, ITX_STREAM_TILE);
         return ITX_E_ARG;
     }

@@ -158,6 +158,12 @@ int itx_engine_wait_slot(itx_engine *e, int slot);
 int itx_engine_submit_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
 /* Classification only (no accumulation): cuskent/binRange.c:196-227 + generic.c:950-970 per record. */
 int itx_engine_classify_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
+/* The lookup alone, on plain intervals: for record i the FIRST row binKeeperFind(chrom of tid[i], pos[i], tmpend[i])
+ * would return (cuskent/binRange.c:196-227, clipping included) — what cpgBedGraphOverlapRepeat takes for a CpG site
+ * (generic.c:1082-1088) — or -1. mapq / flag5 are not looked at (the arrays must exist); no filter, no best-hit rule,
+ * no -c, nothing is accumulated. Chosen rows come back like with classify (slot: staging.hit_row). */
+int itx_engine_first_hit_slot(itx_engine *e, int slot, size_t n);
+int itx_engine_first_hit_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
 int itx_engine_sync(itx_engine *e);
 /* Zero every accumulator. */
 int itx_engine_reset(itx_engine *e);

@@ -149,7 +149,8 @@ struct ItxDevBatch {
 
 // Streaming kernel (itx_stream.hip): one launch classifies n records and, per `what`, does nothing else,
 // accumulates with global atomics (stat: A/B arrays, filter: per-locus counts) or emits keys.
-enum { ITX_DO_CLASSIFY = 0, ITX_DO_ATOMIC_STAT = 1, ITX_DO_ATOMIC_LOCUS = 2, ITX_DO_EMIT = 3 };
+enum { ITX_DO_CLASSIFY = 0, ITX_DO_ATOMIC_STAT = 1, ITX_DO_ATOMIC_LOCUS = 2, ITX_DO_EMIT = 3,
+       ITX_DO_FIND_FIRST = 4 /* plain intervals (pos, tmpend): first overlapping row in binKeeperFind's order, nothing else */ };
 #define ITX_STREAM_LB 5             // workgroups of the streaming kernel per CU its register budget is set for (96 VGPRs)
 // Workgroups of a streaming launch: one full wave of the chip (CUs x ITX_STREAM_LB), each walking one contiguous
 // span of records; ITX_STREAM_BLOCKS overrides (experiments), 2048 bounds the per-region bookkeeping.

@@ -128,6 +128,29 @@ __device__ __forceinline__ int32_t itx_pick(const ACC &A, uint32_t lo, uint32_t 
     return itx_pick_multi(A, low, top, qs, qe, ustart, uend, min_cov);
 }
 
+// The FIRST hit in binKeeperFind's return order (what cpgBedGraphOverlapRepeat takes, generic.c:1084-1088): among the
+// rows overlapping [qs, qe) the one with the smallest list-order rank, or -1.
+template <class ACC>
+__device__ __forceinline__ int32_t itx_pick_first(const ACC &A, uint32_t lo, uint32_t top, int32_t qs, int32_t qe)
+{
+    int32_t best = -1;
+    uint32_t best_rk = 0xffffffffu;
+    for (uint32_t k = top; k > lo;) {
+        --k;
+        int32_t s, e, pb;
+        A.sep(k, s, e, pb);
+        if (clip_ov(s, e, qs, qe) > 0) {
+            const uint32_t rk = A.rk(k);
+            if (rk < best_rk) {
+                best_rk = rk;
+                best = (int32_t)k;
+            }
+        }
+        if (pb <= qs) break;
+    }
+    return best;
+}
+
 // Generic per-lane lookup straight from global memory (any record order). qs/qe already clipped.
 __device__ __forceinline__ int32_t itx_classify_lane(const ItxDevTable &T, uint32_t iv_lo, uint32_t bin_base, int32_t qs, int32_t qe,
                                                      uint32_t ustart, uint32_t uend, float min_cov)
@@ -136,6 +159,12 @@ __device__ __forceinline__ int32_t itx_classify_lane(const ItxDevTable &T, uint3
     const uint32_t top = T.bl[bin_base + ((uint32_t)qe >> T.shift) + 1].x;
     IvGlobal A{T.iv};
     return itx_pick(A, iv_lo, top, qs, qe, ustart, uend, min_cov);
+}
+__device__ __forceinline__ int32_t itx_first_lane(const ItxDevTable &T, uint32_t iv_lo, uint32_t bin_base, int32_t qs, int32_t qe)
+{
+    const uint32_t top = T.bl[bin_base + ((uint32_t)qe >> T.shift) + 1].x;
+    IvGlobal A{T.iv};
+    return itx_pick_first(A, iv_lo, top, qs, qe);
 }
 
 // Wave-wide min / max over all 64 lanes with DPP row shifts and row broadcasts (VALU only; a __shfl_xor

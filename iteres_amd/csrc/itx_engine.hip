@@ -237,7 +237,8 @@ extern "C" int itx_engine_staging(itx_engine *e, int slot, itx_staging *out)
     return ITX_OK;
 }
 
-static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_hit_row, hipStream_t st, bool accumulate)
+enum { RUN_ACCUMULATE = 0, RUN_CLASSIFY = 1, RUN_FIND_FIRST = 2 };
+static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_hit_row, hipStream_t st, int kind)
 {
     if (e->n_tid == 0) {
         itx_set_error("submit before itx_engine_set_tidmap");
@@ -264,13 +265,16 @@ static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_h
     ITX_HIP(hipEventCreate(&b));
     ITX_HIP(hipEventRecord(a, st));
     int rc;
+    const bool accumulate = kind == RUN_ACCUMULATE;
     if (accumulate && e->p.accum == ITX_ACCUM_PARTITION) {
         rc = itx_part_run(e->pw, e->t->dev, P, B, n, d_hit_row, e->u64, e->u32, e->L, st);
     } else {
         size_t span = (n + e->max_blocks - 1) / e->max_blocks;
         span = (span + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
         const unsigned nb = (unsigned)((n + span - 1) / span);
-        const int what = !accumulate ? ITX_DO_CLASSIFY : (e->p.mode == ITX_MODE_STAT ? ITX_DO_ATOMIC_STAT : ITX_DO_ATOMIC_LOCUS);
+        const int what = kind == RUN_FIND_FIRST ? ITX_DO_FIND_FIRST
+                         : !accumulate         ? ITX_DO_CLASSIFY
+                                               : (e->p.mode == ITX_MODE_STAT ? ITX_DO_ATOMIC_STAT : ITX_DO_ATOMIC_LOCUS);
         const ItxEmitPlan none = {nullptr, nullptr, 0, 0};
         rc = itx_launch_stream(what, e->t->dev, P, B, n, span, nb, d_hit_row, e->u64, e->u32, e->L, nullptr, nullptr, none, st);
     }
@@ -283,7 +287,7 @@ static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_h
     return rc;
 }
 
-static int slot_run(itx_engine *e, int slot, size_t n, int has_paired, int want_hits, bool accumulate)
+static int slot_run(itx_engine *e, int slot, size_t n, int has_paired, int want_hits, int kind)
 {
     if (!e || slot < 0 || slot > 1) {
         itx_set_error("itx_engine_submit/classify_slot: bad argument");
@@ -314,7 +318,7 @@ static int slot_run(itx_engine *e, int slot, size_t n, int has_paired, int want_
                      has_paired ? S.d.isize : nullptr};
     ITX_HIP(hipEventRecord(S.copied, S.stream));
     ITX_HIP(hipStreamWaitEvent(e->compute, S.copied, 0));
-    rc = run_batch(e, B, n, want_hits ? S.d.hit_row : nullptr, e->compute, accumulate);
+    rc = run_batch(e, B, n, want_hits ? S.d.hit_row : nullptr, e->compute, kind);
     if (rc) return rc;
     ITX_HIP(hipEventRecord(S.done, e->compute));
     ITX_HIP(hipStreamWaitEvent(S.stream, S.done, 0));
@@ -326,12 +330,17 @@ static int slot_run(itx_engine *e, int slot, size_t n, int has_paired, int want_
 
 extern "C" int itx_engine_submit_slot(itx_engine *e, int slot, size_t n, int has_paired, int want_hits)
 {
-    return slot_run(e, slot, n, has_paired, want_hits, true);
+    return slot_run(e, slot, n, has_paired, want_hits, RUN_ACCUMULATE);
 }
 
 extern "C" int itx_engine_classify_slot(itx_engine *e, int slot, size_t n, int has_paired)
 {
-    return slot_run(e, slot, n, has_paired, 1, false);
+    return slot_run(e, slot, n, has_paired, 1, RUN_CLASSIFY);
+}
+
+extern "C" int itx_engine_first_hit_slot(itx_engine *e, int slot, size_t n)
+{
+    return slot_run(e, slot, n, 0, 1, RUN_FIND_FIRST);
 }
 
 extern "C" int itx_engine_wait_slot(itx_engine *e, int slot)
@@ -362,7 +371,7 @@ extern "C" int itx_engine_submit_device(itx_engine *e, const itx_batch *b, size_
     }
     int rc = use_device(e);
     if (rc) return rc;
-    return run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, true);
+    return run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, RUN_ACCUMULATE);
 }
 
 extern "C" int itx_engine_classify_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream)
@@ -373,7 +382,18 @@ extern "C" int itx_engine_classify_device(itx_engine *e, const itx_batch *b, siz
     }
     int rc = use_device(e);
     if (rc) return rc;
-    return run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, false);
+    return run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, RUN_CLASSIFY);
+}
+
+extern "C" int itx_engine_first_hit_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream)
+{
+    if (!e || !b || !d_hit_row || (n && (!b->tid || !b->pos || !b->tmpend || !b->mapq || !b->flag5))) {
+        itx_set_error("itx_engine_first_hit_device: bad argument");
+        return ITX_E_ARG;
+    }
+    int rc = use_device(e);
+    if (rc) return rc;
+    return run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, RUN_FIND_FIRST);
 }
 
 extern "C" int itx_engine_sync(itx_engine *e)

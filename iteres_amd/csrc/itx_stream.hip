@@ -144,6 +144,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     __shared__ uint32_t s_lut[1024];                           // entries 512.. are zero: records past the end carry fl = 512
     __shared__ uint32_t s_cnt[16];
     extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
+    constexpr bool FIRST = WHAT == ITX_DO_FIND_FIRST;         // cpg lookups: first hit in list order, plain intervals
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     uint4 *win = s_win[w];
@@ -282,9 +283,18 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         }
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-            uint32_t st, en;
-            derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, cur0.x, cur0.y, cur0.z < cur0.w, lut[j], st, en, qs[j], qe[j], q[j], uq[j]);
-            odd = odd || (q[j] && ((int32_t)st != qs[j] || (int32_t)en != qe[j]));
+            if (FIRST) {
+                // a plain interval [pos, tmpend) on a chromosome with rows, clipped like binKeeperFind (binRange.c:204-206)
+                lut[j] = 0;
+                uq[j] = false;
+                qs[j] = imax32(raw[j].pos, 0);
+                qe[j] = imin32(raw[j].tmpend, (int32_t)cur0.y);
+                q[j] = raw[j].fl != 512u && (int32_t)cur0.x >= 0 && cur0.z < cur0.w && qs[j] < qe[j];
+            } else {
+                uint32_t st, en;
+                derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, cur0.x, cur0.y, cur0.z < cur0.w, lut[j], st, en, qs[j], qe[j], q[j], uq[j]);
+                odd = odd || (q[j] && ((int32_t)st != qs[j] || (int32_t)en != qe[j]));
+            }
             anyq = anyq || q[j];
         }
         if (__ballot(odd)) {                                                    // rare
@@ -298,9 +308,15 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                     tr = *reinterpret_cast<const uint4 *>(&P.tidrec[t]);
                     bb = P.tidrec[t].bin_base;
                 }
-                uint32_t st, en;
-                derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, tr.x, tr.y, tr.z < tr.w, lut[j], st, en, qs[j], qe[j], q[j], uq[j]);
-                if (q[j]) classify_global(T, P, tr.z, bb, qs[j], qe[j], st, en, hit[j], sA[j], sB[j], hB[j]);
+                if (FIRST) {
+                    qs[j] = imax32(raw[j].pos, 0);
+                    qe[j] = imin32(raw[j].tmpend, (int32_t)tr.y);
+                    if (ex[j] && (int32_t)tr.x >= 0 && tr.z < tr.w && qs[j] < qe[j]) hit[j] = itx_first_lane(T, tr.z, bb, qs[j], qe[j]);
+                } else {
+                    uint32_t st, en;
+                    derive_one(P, s_lut, raw[j], isz[j], mps[j], tile_pe, tr.x, tr.y, tr.z < tr.w, lut[j], st, en, qs[j], qe[j], q[j], uq[j]);
+                    if (q[j]) classify_global(T, P, tr.z, bb, qs[j], qe[j], st, en, hit[j], sA[j], sB[j], hB[j]);
+                }
                 q[j] = false;
             }
         }
@@ -356,11 +372,13 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                     // bin lists). pbelow only shrinks on the way down and a row that ends at or before qs cannot overlap,
                     // so records that are done just keep stepping, count nothing, and come to rest on the sentinel.
                     uint32_t kk[RPL], hk[RPL];        // hk: window entries of the hits so far, one byte each, newest lowest
+                    uint32_t f_rk[RPL];               // FIRST: smallest list-order rank among the hits so far (hk = its entry)
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
                         const uint32_t top = top_entry(bs.x, qe[j], T.shift, bin_lo, lo_w);   // a shuffle: every lane takes part
                         kk[j] = q[j] ? top : 0u;                  // rows [0, top) <=> entries [1, top]
                         hk[j] = 0;
+                        f_rk[j] = 0xffffffffu;
                     }
                     bool any;
                     do {
@@ -371,11 +389,23 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
                             const int32_t ov = clip_ov((int32_t)v[j].x, (int32_t)v[j].y, qs[j], qe[j]);
-                            hk[j] = ov > 0 ? (hk[j] << 8) | kk[j] : hk[j];
+                            if (FIRST) {
+                                const bool better = ov > 0 && v[j].w < f_rk[j];
+                                f_rk[j] = better ? v[j].w : f_rk[j];
+                                hk[j] = better ? kk[j] : hk[j];
+                            } else {
+                                hk[j] = ov > 0 ? (hk[j] << 8) | kk[j] : hk[j];
+                            }
                             any = any || (int32_t)v[j].z > qs[j];
                             kk[j] = __builtin_elementwise_sub_sat(kk[j], 1u);
                         }
                     } while (__ballot(any));
+                    if (FIRST) {
+#pragma unroll
+                        for (int j = 0; j < RPL; j++) hit[j] = hk[j] ? (int32_t)hk[j] - 1 + (int32_t)lo_w : -1;
+                        __builtin_amdgcn_wave_barrier();                                    // the window is rewritten next tile
+                        goto classified;
+                    }
                     // Best hit (generic.c:950-970): in binKeeperFind's list order, the LAST hit whose coverage exceeds the
                     // previous hit's. All hits of a record share the denominator (end - start) and, for overlaps below
                     // 2^23, distinct integer overlaps give distinct f32 quotients — so with two hits the pick is an integer
@@ -445,9 +475,13 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             } else {                                                            // sparse or unsorted records: global lookups
 #pragma unroll
                 for (int j = 0; j < RPL; j++)
-                    if (q[j]) classify_global(T, P, cur0.z, cur_bb, qs[j], qe[j], (uint32_t)qs[j], (uint32_t)qe[j], hit[j], sA[j], sB[j], hB[j]);
+                    if (q[j]) {
+                        if (FIRST) hit[j] = itx_first_lane(T, cur0.z, cur_bb, qs[j], qe[j]);
+                        else classify_global(T, P, cur0.z, cur_bb, qs[j], qe[j], (uint32_t)qs[j], (uint32_t)qe[j], hit[j], sA[j], sB[j], hB[j]);
+                    }
             }
         }
+    classified:
         ITX_ABLATE_AT(4, (uint32_t)(hit[0] + hit[1]))
 
         // ---- hits (generic.c:1030-1032), per wave
@@ -543,7 +577,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
 #ifdef ITX_ABLATE
     if (sink == 0x7fffff01u) s_cnt[12] = sink;
 #endif
-    if (WHAT != ITX_DO_CLASSIFY) {                        // classify-only launches leave every accumulator alone
+    if (WHAT != ITX_DO_CLASSIFY && !FIRST) {              // classify-only launches leave every accumulator alone
         uint32_t tot[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -561,7 +595,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         }
     }
     __syncthreads();
-    if (WHAT != ITX_DO_CLASSIFY && threadIdx.x < 16 && s_cnt[threadIdx.x])
+    if (WHAT != ITX_DO_CLASSIFY && !FIRST && threadIdx.x < 16 && s_cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&u64[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
     if (WHAT == ITX_DO_EMIT) {
         if (lane == 0) blk_cnt[4 * blockIdx.x + w] = w_keys;
@@ -613,6 +647,9 @@ int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, con
         break;
     case ITX_DO_ATOMIC_LOCUS:
         hipLaunchKernelGGL(k_stream<ITX_DO_ATOMIC_LOCUS>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt, E);
+        break;
+    case ITX_DO_FIND_FIRST:
+        hipLaunchKernelGGL(k_stream<ITX_DO_FIND_FIRST>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt, E);
         break;
     case ITX_DO_EMIT:
         hipLaunchKernelGGL(k_stream<ITX_DO_EMIT>, g, b, (size_t)E.n_part * 4, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0,

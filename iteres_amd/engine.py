@@ -21,7 +21,7 @@ EXPORTS = [
     "itx_last_error", "itx_abi_version", "itx_device_count", "itx_table_create", "itx_table_destroy",
     "itx_table_get_info", "itx_table_cov_offsets", "itx_engine_create", "itx_engine_destroy", "itx_engine_set_tidmap",
     "itx_engine_staging", "itx_engine_submit_slot", "itx_engine_classify_slot", "itx_engine_wait_slot", "itx_engine_submit_device",
-    "itx_engine_classify_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
+    "itx_engine_classify_device", "itx_engine_first_hit_slot", "itx_engine_first_hit_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
     "itx_engine_partial_size", "itx_engine_export_partial", "itx_engine_finish_partial",
 ]
 
@@ -96,6 +96,8 @@ def load():
     L.itx_engine_staging.argtypes = [C.c_void_p, C.c_int, C.POINTER(Staging)]
     L.itx_engine_submit_slot.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int]
     L.itx_engine_classify_slot.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int]
+    L.itx_engine_first_hit_slot.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.itx_engine_first_hit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_void_p, C.c_void_p]
     L.itx_engine_wait_slot.argtypes = [C.c_void_p, C.c_int]
     L.itx_engine_submit_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_void_p, C.c_void_p]
     L.itx_engine_classify_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_size_t, C.c_void_p, C.c_void_p]
@@ -225,6 +227,31 @@ class Engine:
                     mask = np.asarray(veto(off, bufs[s]["hit_row"][:m].copy()), bool)
                     bufs[s]["flag5"][:m] |= mask.astype(np.uint8) * np.uint8(F5_NOLOOKUP)
                 _chk(L.itx_engine_submit_slot(self._h, s, m, int(paired), int(want_hits)), "itx_engine_submit_slot")
+                pending[s] = (off, off + m)
+                off += m
+            s ^= 1
+        return hits
+
+    def first_hits_host(self, tid, start, end):
+        """First row in binKeeperFind's order for every plain interval (itx_engine_first_hit_slot), through the slots."""
+        L = load()
+        n = len(tid)
+        hits = np.empty(n, np.int32)
+        bufs = [self.staging(0), self.staging(1)]
+        pending = [None, None]
+        off, s = 0, 0
+        while off < n or any(p is not None for p in pending):
+            if pending[s] is not None:
+                _chk(L.itx_engine_wait_slot(self._h, s), "itx_engine_wait_slot")
+                a, b = pending[s]
+                hits[a:b] = bufs[s]["hit_row"][: b - a]
+                pending[s] = None
+            if off < n:
+                m = min(self.capacity, n - off)
+                sl = slice(off, off + m)
+                bufs[s]["tid"][:m] = tid[sl]; bufs[s]["pos"][:m] = start[sl]; bufs[s]["tmpend"][:m] = end[sl]
+                bufs[s]["mapq"][:m] = 0; bufs[s]["flag5"][:m] = 0
+                _chk(L.itx_engine_first_hit_slot(self._h, s, m), "itx_engine_first_hit_slot")
                 pending[s] = (off, off + m)
                 off += m
             s ^= 1

@@ -25,7 +25,7 @@
 
 typedef struct {
     uint32_t chrom_id, start, end, item_count;
-    const uint32_t *val;          /* item_count coverage values */
+    const float *val;             /* item_count values, as a section stores them */
     uint64_t file_offset;
 } bw_section;
 
@@ -131,7 +131,7 @@ static bw_sumlist reduce_sections(const bw_section *sec, const size_t *sec_of, c
             const uint32_t chrom_size = chroms[sec[k].chrom_id].size;
             uint32_t start = sec[k].start;
             for (uint32_t i = 0; i < sec[k].item_count; i++) {
-                const double val = (double)(float)(double)sec[k].val[i];      /* "%u" text -> double -> the float a section stores */
+                const double val = (double)sec[k].val[i];
                 const int size = 1;
                 const double sum = size * val;
                 add_to_summary(&L, sec[k].chrom_id, chrom_size, start, start + 1, (uint32_t)size, val, val, sum, sum * val, reduction);
@@ -451,7 +451,8 @@ static int cmp_chrom_name(const void *a, const void *b)
     return strcmp(((const bw_chrom *)a)->name, ((const bw_chrom *)b)->name);
 }
 
-/* names[i] / len[i] / val[i]: the wig blocks (only names with len != 0 belong here, generic.c:83-90) */
+/* names[i] / len[i] / val[i]: the wig blocks (only names with len != 0 belong here, generic.c:83-90); a value is the
+ * float the converter makes of the wig's text: (float)strtod("%u" or "%.4f" of the number) */
 #include <time.h>
 static double bw_t0;
 static void bw_tick(const char *what)
@@ -464,7 +465,7 @@ static void bw_tick(const char *what)
 }
 #define BW_T(x) bw_tick(x)
 
-void write_bigwig(const char *path, const char *wig_name, const char *const *names, const uint32_t *len, const uint32_t *const *val,
+void write_bigwig(const char *path, const char *wig_name, const char *const *names, const uint32_t *len, const float *const *val,
                   size_t n_names)
 {
     const uint32_t block_size = 256, items_per_slot = 1024;                  /* stat.c:157-158 */
@@ -611,8 +612,7 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
                 memcpy(w, &r8, 1); w += 1;
                 memcpy(w, &cnt, 2); w += 2;
                 for (uint32_t j = 0; j < s->item_count; j++) {
-                    const float v = (float)(double)s->val[j];
-                    memcpy(w, &v, 4);
+                    memcpy(w, &s->val[j], 4);
                     w += 4;
                 }
                 const uint32_t unc = (uint32_t)(w - buf);

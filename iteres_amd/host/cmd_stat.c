@@ -173,18 +173,26 @@ int main_stat(int argc, char **argv)
     {
         const char **nm = xcalloc((size_t)rm.reps.n + 1, sizeof *nm);
         uint32_t *ln = xcalloc((size_t)rm.reps.n + 1, sizeof *ln);
-        const uint32_t **va = xcalloc((size_t)rm.reps.n + 1, sizeof *va), **vu = xcalloc((size_t)rm.reps.n + 1, sizeof *vu);
+        const float **va = xcalloc((size_t)rm.reps.n + 1, sizeof *va), **vu = xcalloc((size_t)rm.reps.n + 1, sizeof *vu);
+        /* the converter reads "%u" back as a double and stores a float */
+        float *fa = xmalloc(sizeof(float) * (info.cov_len + 1)), *fu = xmalloc(sizeof(float) * (info.cov_len + 1));
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)info.cov_len; i++) {
+            fa[i] = (float)(double)res.cov[i];
+            fu[i] = (float)(double)res.cov_uniq[i];
+        }
         size_t k = 0;
         for (uint32_t i = 0; i < rm.reps.n; i++)
             if (rm.rep_len[i]) {
                 nm[k] = rm.reps.name[i];
                 ln[k] = rm.rep_len[i];
-                va[k] = res.cov + cov_off[i];
-                vu[k] = res.cov_uniq + cov_off[i];
+                va[k] = fa + cov_off[i];
+                vu[k] = fu + cov_off[i];
                 k++;
             }
         write_bigwig(outBigWig, outWig, nm, ln, va, k);
         write_bigwig(outBigWigUniq, outWigUniq, nm, ln, vu, k);
+        free(fa); free(fu);
         free(nm); free(ln); free(va); free(vu);
     }
 

@@ -135,8 +135,15 @@ void write_filter_out(const rmsk_t *rm, const uint32_t *locus_cnt, char **locus_
                       const char *subfam, unsigned long long reads_num);
 
 /* bigwig.c: the bigWig of one set of wig blocks (stat.c:156-158); only names with a consensus length belong here */
-void write_bigwig(const char *path, const char *wig_name, const char *const *names, const uint32_t *len, const uint32_t *const *val,
+void write_bigwig(const char *path, const char *wig_name, const char *const *names, const uint32_t *len, const float *const *val,
                   size_t n_names);
+/* tables.c: a whole text file in memory, through the same openers as the rmsk file (plain, .gz/.Z, .bz2, .zip) */
+char *slurp_text(const char *path, size_t *len);
+
+int main_cpgstat(int argc, char **argv);
+int main_cpgfilter(int argc, char **argv);
+
+void write_cpg_loci(const rmsk_t *rm, const int *cpg_count, const double *cpg_total, const char *path, const char *subfam, double threshold);
 
 int main_stat(int argc, char **argv);
 int main_filter(int argc, char **argv);

@@ -1,6 +1,6 @@
 /* main.c — command dispatch of the drop-in `iteres` (iteres.c:3-29 of the reference). stat and filter are the
- * hot-path commands rebuilt on the MI355X engine; cpgstat / cpgfilter (bedGraph input, floating-point sums) are
- * outside this build's scope and say so. */
+ * alignment commands rebuilt on the MI355X engine; cpgstat / cpgfilter (bedGraph input) use the engine's lookup and add
+ * their floating-point sums up on the host in file order (cmd_cpg.c). */
 #include "itx_host.h"
 
 #include <omp.h>
@@ -34,10 +34,9 @@ int main(int argc, char *argv[])
     }
     if (strcmp(argv[1], "stat") == 0) return main_stat(argc - 1, argv + 1);
     else if (strcmp(argv[1], "filter") == 0) return main_filter(argc - 1, argv + 1);
-    else if (strcmp(argv[1], "cpgstat") == 0 || strcmp(argv[1], "cpgfilter") == 0) {
-        fprintf(stderr, "[iteres] '%s' is not part of the MI355X build (only stat and filter are); use the reference binary for it\n", argv[1]);
-        return 1;
-    } else {
+    else if (strcmp(argv[1], "cpgstat") == 0) return main_cpgstat(argc - 1, argv + 1);
+    else if (strcmp(argv[1], "cpgfilter") == 0) return main_cpgfilter(argc - 1, argv + 1);
+    else {
         fprintf(stderr, "[iteres] unrecognized command '%s'\n", argv[1]);
         return 1;
     }

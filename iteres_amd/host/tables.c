@@ -271,6 +271,28 @@ int64_t sizes_get(const sizes_t *s, const char *name, int64_t dflt)
         }                                                         \
     } while (0)
 
+/* the whole file in memory (also when it comes through a decompressor pipe), NUL-terminated */
+char *slurp_text(const char *path, size_t *len)
+{
+    lines_t l;
+    lines_open(&l, path);
+    size_t flen = 0, fcap = 1u << 24;
+    char *text = xmalloc(fcap + 1);
+    for (;;) {
+        const size_t got = fread(text + flen, 1, fcap - flen, l.f);
+        flen += got;
+        if (got == 0) break;
+        if (flen == fcap) {
+            fcap *= 2;
+            text = xrealloc(text, fcap + 1);
+        }
+    }
+    text[flen] = 0;
+    lines_close(&l);
+    *len = flen;
+    return text;
+}
+
 /* The rmsk file is parsed in pieces of whole lines, one per thread, each with the reference's row-by-row bookkeeping
  * (generic.c:1578-1707) on its own tables; the pieces are then joined in file order, which gives every name the id it
  * would have got from one pass (ids are first-appearance ranks, and the pieces are contiguous). */
@@ -418,23 +440,9 @@ static void rmsk_parse_piece(char *text, size_t lo, size_t hi, size_t flen, cons
 void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_sizes, int filter_field, const char *filter_name,
                rmsk_t *r)
 {
-    lines_t l;
     memset(r, 0, sizeof *r);
-    /* the whole file in memory (also when it comes through a decompressor pipe) */
-    lines_open(&l, path);
-    size_t flen = 0, fcap = 1u << 24;
-    char *text = xmalloc(fcap + 1);
-    for (;;) {
-        const size_t got = fread(text + flen, 1, fcap - flen, l.f);
-        flen += got;
-        if (got == 0) break;
-        if (flen == fcap) {
-            fcap *= 2;
-            text = xrealloc(text, fcap + 1);
-        }
-    }
-    text[flen] = 0;
-    lines_close(&l);
+    size_t flen = 0;
+    char *text = slurp_text(path, &flen);
     int T = omp_get_max_threads();
     if (T < 1) T = 1;
     if ((size_t)T > flen / 65536 + 1) T = (int)(flen / 65536 + 1);

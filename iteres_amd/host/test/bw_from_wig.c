@@ -17,7 +17,8 @@ int main(int argc, char **argv)
     FILE *f = fopen(argv[1], "r");
     if (!f) return 3;
     char **names = NULL;
-    uint32_t *len = NULL, **val = NULL;
+    uint32_t *len = NULL;
+    float **val = NULL;
     size_t n = 0, cap = 0, vcap = 0;
     char *line = NULL;
     size_t lcap = 0;
@@ -38,15 +39,15 @@ int main(int argc, char **argv)
         } else if (n && line[0] != '\n') {
             if (len[n - 1] == vcap) {
                 vcap = vcap ? vcap * 2 : 1024;
-                val[n - 1] = realloc(val[n - 1], vcap * sizeof(uint32_t));
+                val[n - 1] = realloc(val[n - 1], vcap * sizeof(float));
             }
-            val[n - 1][len[n - 1]++] = (uint32_t)strtoul(line, NULL, 10);
+            val[n - 1][len[n - 1]++] = (float)strtod(line, NULL);          /* lineFileNeedDouble, then the packed float */
         }
     }
     fclose(f);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    write_bigwig(argv[2], argv[1], (const char *const *)names, len, (const uint32_t *const *)val, n);
+    write_bigwig(argv[2], argv[1], (const char *const *)names, len, (const float *const *)val, n);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (getenv("ITX_TIMING")) fprintf(stderr, "[itx timing] write_bigwig %.3f s\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
     return 0;

@@ -158,17 +158,10 @@ static int lo_cmp(const void *a, const void *b)
     return x->row > y->row ? -1 : (x->row < y->row ? 1 : 0);      /* list head = newest insertion (binRange.c:185) */
 }
 
-void write_filter_out(const rmsk_t *rm, const uint32_t *locus_cnt, char **locus_names, const char *path, int readlist, int threshold,
-                      const char *subfam, unsigned long long reads_num)
+/* The loci of a table in binKeeper order: hashRmsk's chromosome order (names_kent_order), and for every chromosome its
+ * rows with their bin numbers, to be sorted by lo_cmp (cuskent/binRange.c:365-392). */
+static struct lo *loci_prepare(const rmsk_t *rm, uint32_t **corder_out, size_t **cnt_out, size_t **beg_out)
 {
-    FILE *out = must_open(path, "w");
-    int j = 0;
-    if (readlist)
-        fprintf(out, "%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n", "#chr", "start", "end", "length", "repName", "repClass", "repFamily",
-                "readsCount", "RPKM", "RPM", "readsList");
-    else
-        fprintf(out, "%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n", "#chr", "start", "end", "length", "repName", "repClass", "repFamily",
-                "readsCount", "RPKM", "RPM");
     const uint32_t NC = rm->chroms.n;
     uint32_t *corder = xmalloc(sizeof(uint32_t) * (NC + 1));
     names_kent_order(&rm->chroms, 12, corder);                  /* hashRmsk = newHash(0): 2^12 buckets */
@@ -184,6 +177,28 @@ void write_filter_out(const rmsk_t *rm, const uint32_t *locus_cnt, char **locus_
         e->bin = bin_of_range((int)rm->rows[r].start, (int)rm->rows[r].end);
         e->row = (uint32_t)r;
     }
+    free(fill);
+    *corder_out = corder;
+    *cnt_out = cnt;
+    *beg_out = beg;
+    return lo;
+}
+
+void write_filter_out(const rmsk_t *rm, const uint32_t *locus_cnt, char **locus_names, const char *path, int readlist, int threshold,
+                      const char *subfam, unsigned long long reads_num)
+{
+    FILE *out = must_open(path, "w");
+    int j = 0;
+    if (readlist)
+        fprintf(out, "%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n", "#chr", "start", "end", "length", "repName", "repClass", "repFamily",
+                "readsCount", "RPKM", "RPM", "readsList");
+    else
+        fprintf(out, "%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n", "#chr", "start", "end", "length", "repName", "repClass", "repFamily",
+                "readsCount", "RPKM", "RPM");
+    const uint32_t NC = rm->chroms.n;
+    uint32_t *corder;
+    size_t *cnt, *beg;
+    struct lo *lo = loci_prepare(rm, &corder, &cnt, &beg);
     for (uint32_t k = 0; k < NC; k++) {
         const uint32_t c = corder[k];
         qsort(lo + beg[c], cnt[c], sizeof *lo, lo_cmp);
@@ -205,7 +220,37 @@ void write_filter_out(const rmsk_t *rm, const uint32_t *locus_cnt, char **locus_
     fclose(out);
     fprintf(stderr, "* Total %d [%s] TEs have at least %d reads mapped.\n", j, subfam, threshold);
     free(lo);
-    free(fill);
+    free(cnt);
+    free(beg);
+    free(corder);
+}
+
+/* writeFilterOutMRE, generic.c:1748-1772 */
+void write_cpg_loci(const rmsk_t *rm, const int *cpg_count, const double *cpg_total, const char *path, const char *subfam, double threshold)
+{
+    FILE *out = must_open(path, "w");
+    int j = 0;
+    fprintf(out, "%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n", "#chr", "start", "end", "length", "repName", "repClass", "repFamily", "covered_CpG_site",
+            "total_CpG_score");
+    const uint32_t NC = rm->chroms.n;
+    uint32_t *corder;
+    size_t *cnt, *beg;
+    struct lo *lo = loci_prepare(rm, &corder, &cnt, &beg);
+    for (uint32_t k = 0; k < NC; k++) {
+        const uint32_t c = corder[k];
+        qsort(lo + beg[c], cnt[c], sizeof *lo, lo_cmp);
+        for (size_t i = beg[c]; i < beg[c] + cnt[c]; i++) {
+            const uint32_t r = lo[i].row;
+            const itx_row *os = &rm->rows[r];
+            if (!(cpg_total[r] > threshold)) continue;
+            j++;
+            fprintf(out, "%s\t%d\t%d\t%d\t%s\t%s\t%s\t%d\t%.3f\n", rm->chroms.name[c], (int)os->start, (int)os->end, (int)(os->end - os->start),
+                    rm->reps.name[os->rep], rm->clas.name[os->cla], rm->fams.name[os->fam], cpg_count[r], cpg_total[r]);
+        }
+    }
+    fclose(out);
+    fprintf(stderr, "* Total %d [%s] TEs have CpG score larger than %.3f.\n", j, subfam, threshold);
+    free(lo);
     free(cnt);
     free(beg);
     free(corder);

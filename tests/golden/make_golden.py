@@ -65,7 +65,7 @@ def run_ref(case_dir, run_name, cmd, opts, aln, tmp, prefix="out"):
             "files": files, "bigwig_sha256": bigwigs, "stderr_tail": pr.stderr.replace("\r", "\n").strip().split("\n")[-3:]}
 
 
-def emit_case(name, table, reads, runs, extra_rmsk_rows=(), extra_chrom_sizes=(), bam=True, sam=True, with_seq=True):
+def emit_case(name, table, reads, runs, extra_rmsk_rows=(), extra_chrom_sizes=(), bam=True, sam=True, with_seq=True, extra_files=None):
     case_dir = os.path.join(HERE, name)
     if os.path.isdir(case_dir):
         shutil.rmtree(case_dir)
@@ -75,12 +75,16 @@ def emit_case(name, table, reads, runs, extra_rmsk_rows=(), extra_chrom_sizes=()
         synth.write_sizes(os.path.join(tmp, "rep.sizes"), table.rep_len.items())
         synth.write_rmsk(os.path.join(tmp, "rmsk.txt"), table, extra_rmsk_rows)
         alns = []
-        if sam:
+        if sam and reads is not None:
             synth.write_sam(os.path.join(tmp, "reads.sam"), reads, with_seq=with_seq)
             alns.append("reads.sam")
-        if bam:
+        if bam and reads is not None:
             synth.write_bam(os.path.join(tmp, "reads.bam"), reads, with_seq=with_seq)
             alns.append("reads.bam")
+        for fn, text in (extra_files or {}).items():
+            with open(os.path.join(tmp, fn), "w") as f:
+                f.write(text)
+            alns.append(fn)
         for fn in ["chrom.sizes", "rep.sizes", "rmsk.txt"] + alns:
             _store(os.path.join(tmp, fn), os.path.join(case_dir, "in", fn))
         man = {"case": name, "inputs": sorted(os.listdir(os.path.join(case_dir, "in"))), "runs": []}
@@ -296,9 +300,45 @@ def case_sidechan():
     emit_case("sidechan", t, r, runs)
 
 
+def case_cpg():
+    """cpgstat / cpgfilter (generic.c:1064-1139): CpG sites with scores from a bedGraph file; the sums are doubles added
+    in file order, the lookup takes the FIRST row binKeeperFind returns."""
+    chroms = [("chrA", 3000000), ("chrB", 700000), ("chrC", 140000)]
+    t = synth.make_table(401, chroms, 5000, n_names=200, n_fams=25, n_clas=8, overlap_frac=0.12, shuffle_frac=0.05)
+    rng = np.random.default_rng(402)
+    lines = ["# CpG methylation scores", ""]
+    n = 40000
+    ci = rng.choice(3, n, p=[0.75, 0.2, 0.05])
+    pos = (rng.random(n) * np.array([c[1] for c in chroms])[ci]).astype(np.int64)
+    order = np.lexsort((pos, ci))
+    order[5000:5400] = order[5000:5400][::-1]                      # a stretch out of order: the sums follow the file
+    for k in order:
+        c, p0 = chroms[ci[k]][0], int(pos[k])
+        score = float(rng.choice([rng.random() * 3, rng.random() * 1e-3, 10 ** rng.uniform(-6, 2), 0.1, 1 / 3]))
+        end = p0 + 2 if rng.random() < 0.97 else p0 + int(rng.integers(1, 400))
+        lines.append(f"{c}\t{p0}\t{end}\t{score!r}")
+    lines[700] = "   # an indented comment"
+    lines.insert(900, "   ")
+    lines.append("chrNoRepeats\t100\t102\t1.5")                    # a chromosome without rows
+    lines.append(f"chrA\t{chroms[0][1] - 1}\t{chroms[0][1] + 5}\t2.25\textra\tfields")
+    lines.append("chrB 10 12 0.75")                                  # blanks separate fields too
+    bed = "\n".join(lines) + "\n"
+    fam = t.fams[int(t.fam_of_row[7])]
+    cla = t.clas[int(t.cla_of_row[11])]
+    runs = [
+        ("cpgstat_w", "cpgstat", ["-w"], "cpg.bedGraph"),
+        ("cpgstat", "cpgstat", [], "cpg.bedGraph"),
+        ("cpgfilter_all", "cpgfilter", [], "cpg.bedGraph"),
+        ("cpgfilter_n_t", "cpgfilter", ["-n", "Rep3", "-t", "0.5"], "cpg.bedGraph"),
+        ("cpgfilter_f", "cpgfilter", ["-f", fam], "cpg.bedGraph"),
+        ("cpgfilter_c_t", "cpgfilter", ["-c", cla, "-t", "2"], "cpg.bedGraph"),
+    ]
+    emit_case("cpg", t, None, runs, bam=False, sam=False, extra_files={"cpg.bedGraph": bed})
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -C oracle ref")
-    which = sys.argv[1:] or ["quirks", "mid", "manynames", "cfg1", "sidechan"]
+    which = sys.argv[1:] or ["quirks", "mid", "manynames", "cfg1", "sidechan", "cpg"]
     for w in which:
         globals()["case_" + w]()

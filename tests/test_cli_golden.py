@@ -45,7 +45,15 @@ def test_cli_matches_reference_files(case, run_name, exe, tmp_path):
         assert refio.bigwig_digest(got_path.read_bytes()) == want, f"{case}/{run_name}/{fn}: decoded bigWig differs"
     # the banners the reference prints around the phases are part of the boundary too
     err = pr.stderr.replace("\r", "\n")
-    if run["cmd"] == "stat":
+    if run["cmd"] == "cpgstat":
+        for banner in ("* Start to parse the rmsk file", "* Start to parse the bedGraph file", "* Processed CpG sites:", "* CpG sites in Repeats:",
+                       "* Writing stats and Wig file", "* Generating bigWig files", "* Done, time used"):
+            assert banner in err
+    elif run["cmd"] == "cpgfilter":
+        for banner in ("* Start to parse the rmsk file", "* Start to parse the bedGraph file", "* Preparing the output file", "* Done, time used"):
+            assert banner in err
+        assert run["stderr_tail"][-2] in err                      # "* Total N [name] TEs have CpG score larger than T."
+    elif run["cmd"] == "stat":
         for banner in ("* Provided 1 BAM/SAM file(s)", "* Parsing the rmsk file", "* Parsing the SAM/BAM file", "* Writing stats and Wig file",
                        "* Preparing report file", "* Done, time used"):
             assert banner in err

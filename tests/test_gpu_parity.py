@@ -18,7 +18,7 @@ import os
 ACCUMS = [int(x) for x in os.environ.get("ITX_TEST_ACCUMS", "1,2").split(",")]
 
 
-@pytest.mark.parametrize("case,run_name", [r for r in gc.list_runs() if r[0] != "manynames"])
+@pytest.mark.parametrize("case,run_name", [r for r in gc.list_runs("stat") + gc.list_runs("filter") if r[0] != "manynames"])
 @pytest.mark.parametrize("accum", ACCUMS)
 def test_golden_case(case, run_name, accum):
     run = gc.manifest_run(case, run_name)
@@ -165,6 +165,40 @@ def test_nolookup_and_veto(accum):
         eres, ores, hits = ec.run_both(rows, cs, rl, nf, nc, dict(), t2c, rd, batch_capacity=50_001, accum=accum, **kw)
         ec.assert_same(eres, ores, hits, False, len(rows))
     assert (ores["hit_row"] >= 0).sum() > 10_000
+
+
+def test_first_hit_lookup():
+    """itx_engine_first_hit_*: the first row binKeeperFind returns for a plain interval (the cpg commands' lookup,
+    generic.c:1082-1088) — sorted CpG-like sites, unsorted intervals of every size, chromosome edges, nested rows."""
+    chroms = [("c1", 30_000_000), ("c2", 6_000_000), ("c3", 400_000)]
+    rows, cs, rl, nf, nc, t2c, _ = _synth_case(91, 80_000, 10, chroms, overlap=0.15)
+    ot = ec.oracle_table(rows, cs, rl, nf, nc)
+    rng = np.random.default_rng(92)
+    t = eng.Table(rows, cs, rl, nf, nc)
+    e = eng.Engine(t, dict(), batch_capacity=70_001)
+    e.set_tidmap(list(t2c))
+    m = 200_000
+    # CpG-like: sorted 2-bp sites; then unsorted intervals from 1 bp to 300 kb, some hanging over the chromosome ends
+    tid = np.sort(rng.integers(0, 3, m)).astype(np.int32)
+    pos = np.zeros(m, np.int64)
+    for c in range(3):
+        k = tid == c
+        pos[k] = np.sort(rng.integers(0, int(cs[c]) - 1, int(k.sum())))
+    cases = [(tid, pos.astype(np.int32), (pos + 2).astype(np.int32))]
+    tid2 = rng.integers(-1, 5, m).astype(np.int32)                       # -1 and 4: no such chromosome; 3 = chrNotInSizes
+    size2 = np.array([int(cs[c]) if 0 <= c < 3 else 5000 for c in tid2])
+    st2 = (rng.random(m) * (size2 + 2000) - 1000).astype(np.int64)
+    ln2 = (2 ** rng.uniform(0, 18, m)).astype(np.int64)
+    cases.append((tid2, st2.astype(np.int32), (st2 + ln2).astype(np.int32)))
+    for tid_, s_, e_ in cases:
+        got = e.first_hits_host(tid_, s_, e_)
+        idx = rng.choice(m, 6000, replace=False)                         # the oracle's find is a Python-level call: sample
+        for i in idx:
+            c = int(t2c[tid_[i]]) if 0 <= tid_[i] < len(t2c) else -1
+            h = ot.find(c, int(s_[i]), int(e_[i])) if c >= 0 else []
+            assert int(got[i]) == (int(h[0]) if len(h) else -1), (i, int(tid_[i]), int(s_[i]), int(e_[i]))
+        assert (got >= 0).mean() > 0.2
+    e.close(); t.close(); ot.close()
 
 
 def test_properties_at_scale():

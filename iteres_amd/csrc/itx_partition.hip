@@ -172,12 +172,21 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0,
     for (uint32_t q = 0; q < 4; q++) {                         // the four waves of the emitting workgroup filled a quarter each
         const uint32_t total = blk_cnt[4 * blockIdx.x + q];
         const uint2 *in = keys0 + 2 * (size_t)blockIdx.x * span + (size_t)q * (span / 2);
+        // software-pipelined: the loads of the next 2048 keys are in flight while the current ones find their places
+        uint2 nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t idx = u * PB + threadIdx.x;
+            nxt[u] = idx < total ? in[idx] : make_uint2(0, 0xffffffffu);
+        }
         for (uint32_t r0 = 0; r0 < total; r0 += U * PB) {
             uint2 key[U];
 #pragma unroll
+            for (int u = 0; u < U; u++) key[u] = nxt[u];
+#pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t idx = r0 + u * PB + threadIdx.x;
-                key[u] = idx < total ? in[idx] : make_uint2(0, 0xffffffffu);
+                const uint32_t idx = r0 + U * PB + u * PB + threadIdx.x;
+                nxt[u] = idx < total ? in[idx] : make_uint2(0, 0xffffffffu);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -209,15 +218,15 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
             s_b[k] = 0;
         }
         __syncthreads();
-        for (uint32_t k0 = item.y; k0 < item.z; k0 += 4 * HB) {          // 4 loads in flight per thread
-            uint32_t key[4];
+        for (uint32_t k0 = item.y; k0 < item.z; k0 += 8 * HB) {          // 8 loads in flight per thread
+            uint32_t key[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 const uint32_t k = k0 + u * HB + threadIdx.x;
                 key[u] = k < item.z ? keys1[k] : 0xffffffffu;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 if (key[u] != 0xffffffffu) {
                     const uint32_t sl = key[u] >> 16, type = key[u] & 3u, len = (key[u] >> 3) & (ITX_W - 1);
                     const uint32_t v = 1u | ((key[u] & 4u) << 14);
@@ -239,25 +248,28 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
                 if (!(anya || anyb)) continue;
                 const size_t g = (size_t)slot0 + k;
                 if (k + 4 <= lim) {
+                    // the (up to) four 16-byte loads go out together, then the adds and the stores
+                    const bool ua = (a.x | a.y | a.z | a.w) >> 16, ub = (b.x | b.y | b.z | b.w) >> 16;
+                    uint4 xa = make_uint4(0, 0, 0, 0), ya = xa, xb = xa, yb = xa;
+                    if (anya) xa = *reinterpret_cast<const uint4 *>(&u32[L.a_all + g]);
+                    if (ua) ya = *reinterpret_cast<const uint4 *>(&u32[L.a_uniq + g]);
+                    if (anyb) xb = *reinterpret_cast<const uint4 *>(&u32[L.b_all + g]);
+                    if (ub) yb = *reinterpret_cast<const uint4 *>(&u32[L.b_uniq + g]);
                     if (anya) {
-                        uint4 x = *reinterpret_cast<uint4 *>(&u32[L.a_all + g]);
-                        x.x += a.x & 0xffffu; x.y += a.y & 0xffffu; x.z += a.z & 0xffffu; x.w += a.w & 0xffffu;
-                        *reinterpret_cast<uint4 *>(&u32[L.a_all + g]) = x;
-                        if ((a.x | a.y | a.z | a.w) >> 16) {
-                            uint4 y = *reinterpret_cast<uint4 *>(&u32[L.a_uniq + g]);
-                            y.x += a.x >> 16; y.y += a.y >> 16; y.z += a.z >> 16; y.w += a.w >> 16;
-                            *reinterpret_cast<uint4 *>(&u32[L.a_uniq + g]) = y;
-                        }
+                        xa.x += a.x & 0xffffu; xa.y += a.y & 0xffffu; xa.z += a.z & 0xffffu; xa.w += a.w & 0xffffu;
+                        *reinterpret_cast<uint4 *>(&u32[L.a_all + g]) = xa;
+                    }
+                    if (ua) {
+                        ya.x += a.x >> 16; ya.y += a.y >> 16; ya.z += a.z >> 16; ya.w += a.w >> 16;
+                        *reinterpret_cast<uint4 *>(&u32[L.a_uniq + g]) = ya;
                     }
                     if (anyb) {
-                        uint4 x = *reinterpret_cast<uint4 *>(&u32[L.b_all + g]);
-                        x.x += b.x & 0xffffu; x.y += b.y & 0xffffu; x.z += b.z & 0xffffu; x.w += b.w & 0xffffu;
-                        *reinterpret_cast<uint4 *>(&u32[L.b_all + g]) = x;
-                        if ((b.x | b.y | b.z | b.w) >> 16) {
-                            uint4 y = *reinterpret_cast<uint4 *>(&u32[L.b_uniq + g]);
-                            y.x += b.x >> 16; y.y += b.y >> 16; y.z += b.z >> 16; y.w += b.w >> 16;
-                            *reinterpret_cast<uint4 *>(&u32[L.b_uniq + g]) = y;
-                        }
+                        xb.x += b.x & 0xffffu; xb.y += b.y & 0xffffu; xb.z += b.z & 0xffffu; xb.w += b.w & 0xffffu;
+                        *reinterpret_cast<uint4 *>(&u32[L.b_all + g]) = xb;
+                    }
+                    if (ub) {
+                        yb.x += b.x >> 16; yb.y += b.y >> 16; yb.z += b.z >> 16; yb.w += b.w >> 16;
+                        *reinterpret_cast<uint4 *>(&u32[L.b_uniq + g]) = yb;
                     }
                 } else {                                         // the last, partial group of the slot space
                     const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};

@@ -6,6 +6,8 @@
 
 #include "../../include/iteres_amd.h"
 
+#define ITX_LOGW 13         // slots per partition / LDS window of the partition path (W = 8192)
+
 // One interval of the device table, 32 bytes (two dwordx4 loads). Intervals of a chromosome are
 // contiguous and sorted by (start, file order).
 struct __attribute__((aligned(16))) ItxIv {
@@ -26,6 +28,9 @@ static_assert(sizeof(ItxIv) == 32, "ItxIv must be 32 bytes");
 struct ItxDevTable {
     const ItxIv    *iv;         // [n_rows]
     const int32_t  *orig;       // [n_rows] sorted index -> caller's row index
+    const uint32_t *row_unit;   // [n_rows] sorted index -> unit (ITX_ACCUM_ATOMIC counts reads per unit directly)
+    const uint32_t *unit_slot;  // [n_units + 1] first slot of every unit
+    const uint32_t *part_unit;  // [n_slots >> ITX_LOGW, + 2] first unit that reaches into each window of 2^ITX_LOGW slots
     const uint2    *bl;         // binned index, one slice per chromosome (ItxTidRec.bin_base), per bin b of 2^shift bp:
                                 //   .x = first index with s >= (b << shift)          (upper bound of "s < x" queries)
                                 //   .y = first index whose prefix-max end > (b << shift)      (lower bound of what can still overlap)
@@ -47,21 +52,22 @@ struct __attribute__((aligned(16))) ItxTidRec {
 static_assert(sizeof(ItxTidRec) == 32, "ItxTidRec must be 32 bytes");
 
 // Raw device accumulators (element offsets).
-//   u64: cnt[16]
-//   u32: A_all[n_slots] | A_uniq[n_slots] | B_all[n_slots] | B_uniq[n_slots] | locus[n_rows]
-// A = "a read's consensus range starts here" counts, B = "ends here" counts, per slot. A unit's coverage
-// is the prefix sum of A-B over its slots and its read count is sum(A): every classified read records
-// exactly one start (in the unit's extra slot when it adds no coverage). Read counts of names, families
-// and classes are sums of unit counts. All sums are mod 2^32 / 2^64 like the reference's counters.
+//   u64: cnt[16] | unit_all[n_units] | unit_uniq[n_units]          reads that chose a row of the unit (all / MAPQ >= -Q)
+//   u32: D_all[n_slots] | D_uniq[n_slots] | locus[n_rows]          D = starts - ends of consensus ranges, per slot
+// A unit's coverage is the prefix sum of D over its slots (mod 2^32 like the reference's unsigned counters); read counts
+// of names, families and classes are sums of unit counts. The u64 block and the two D arrays ARE the partial a
+// multi-GPU driver reduces (include/iteres_amd.h: itx_engine_export_partial).
 struct ItxAccumLayout {
-    uint64_t a_all, a_uniq, b_all, b_uniq, locus, n_u32;
+    uint64_t d_all, d_uniq, locus, n_u32;
+    uint64_t n_units;          // u64: unit_all at 16, unit_uniq at 16 + n_units
 };
-static inline ItxAccumLayout itx_accum_layout(uint64_t n_slots, uint64_t n_rows)
+static inline ItxAccumLayout itx_accum_layout(uint64_t n_slots, uint64_t n_rows, uint64_t n_units)
 {
     ItxAccumLayout L;
     const uint64_t st = (n_slots + 63) & ~uint64_t(63);      // each array starts 256-byte aligned (16-byte vector updates)
-    L.a_all = 0; L.a_uniq = st; L.b_all = 2 * st; L.b_uniq = 3 * st; L.locus = 4 * st;
+    L.d_all = 0; L.d_uniq = st; L.locus = 2 * st;
     L.n_u32 = L.locus + n_rows;
+    L.n_units = n_units;
     return L;
 }
 // The partial a multi-GPU driver reduces (include/iteres_amd.h: itx_engine_export_partial):
@@ -86,6 +92,8 @@ struct itx_table {
     uint32_t *d_unit_slot;   // [n_units+1]
     uint4    *d_unit_ids;    // [n_units] (rep, fam, cla, solo)
     uint64_t *d_unit_covoff; // [n_units] offset of the unit's repName inside the concatenated coverage vectors
+    uint32_t *d_row_unit;    // [n_rows] (sorted order)
+    uint32_t *d_part_unit;
 };
 
 void itx_set_error(const char *fmt, ...);

@@ -23,7 +23,7 @@ struct itx_engine {
     itx_params p;
     size_t cap;
     ItxAccumLayout L;
-    uint64_t *u64;        // cnt[16]
+    uint64_t *u64;        // cnt[16] | unit_all[n_units] | unit_uniq[n_units]
     uint32_t *u32;        // raw A/B slot arrays + per-locus counts
     ItxTidRec *d_tidrec;
     int n_tid, cap_tid;
@@ -82,7 +82,7 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     if (e->p.accum == ITX_ACCUM_DEFAULT) e->p.accum = ITX_ACCUM_PARTITION;
     if (e->p.mode == ITX_MODE_FILTER) e->p.accum = ITX_ACCUM_ATOMIC;   // per-locus counts: one atomic per run of equal rows
     e->cap = batch_capacity;
-    e->L = itx_accum_layout(t->n_slots, t->n_rows);
+    e->L = itx_accum_layout(t->n_slots, t->n_rows, t->n_units);
     e->u64 = nullptr;
     e->u32 = nullptr;
     e->d_tidrec = nullptr;
@@ -99,8 +99,8 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     memset(e->stage_ms, 0, sizeof e->stage_ms);
     e->pw = nullptr;
     e->max_blocks = itx_stream_blocks(t->device);
-    hipError_t he = hipMalloc((void **)&e->u64, 16 * sizeof(uint64_t));
-    if (he == hipSuccess) he = hipMemset(e->u64, 0, 16 * sizeof(uint64_t));
+    hipError_t he = hipMalloc((void **)&e->u64, (partial_u64(e) + 2) * sizeof(uint64_t));
+    if (he == hipSuccess) he = hipMemset(e->u64, 0, (partial_u64(e) + 2) * sizeof(uint64_t));
     if (he == hipSuccess) he = hipMalloc((void **)&e->u32, (e->L.n_u32 + 4) * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(e->u32, 0, (e->L.n_u32 + 4) * sizeof(uint32_t));
     if (he != hipSuccess) {
@@ -428,7 +428,7 @@ extern "C" int itx_engine_reset(itx_engine *e)
     if (!e) return ITX_E_ARG;
     int rc = itx_engine_sync(e);
     if (rc) return rc;
-    ITX_HIP(hipMemset(e->u64, 0, 16 * sizeof(uint64_t)));
+    ITX_HIP(hipMemset(e->u64, 0, partial_u64(e) * sizeof(uint64_t)));
     ITX_HIP(hipMemset(e->u32, 0, e->L.n_u32 * sizeof(uint32_t)));
     fold_events(e);
     e->kernel_ms = 0;

@@ -1,7 +1,7 @@
 // itx_finalize.hip — end-of-stream kernels: raw accumulators -> compact partial (what ranks all-reduce)
 // -> the arrays the reference's writers consume (generic.c:72-113, 1709-1746).
 //
-//   k_export_unit   per unit: D = A - B for both coverage arrays, read counts = sum(A)
+//   export          the accumulators already are the partial (unit read counts, D = starts - ends): device copies
 //   k_finish_unit   per unit: coverage = prefix sum of D (mod 2^32, like bp_total's unsigned int),
 //                   counts added to the unit's repName / repFamily / repClass
 //   k_permute_locus filter mode: per-locus counts from sorted-row order to the caller's row order
@@ -18,40 +18,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
         if (lane >= o) v += t;
     }
     return v;
-}
-
-__global__ __launch_bounds__(FB) void k_export_unit(const uint32_t *__restrict__ unit_slot, const uint64_t *__restrict__ u64,
-                                                    const uint32_t *__restrict__ u32, ItxAccumLayout L, uint32_t n_units,
-                                                    uint32_t n_slots, uint64_t *__restrict__ p64, uint32_t *__restrict__ p32)
-{
-    __shared__ unsigned long long s_sum[2];
-    const uint32_t u = blockIdx.x;
-    if (u == 0 && threadIdx.x < 16) p64[threadIdx.x] = u64[threadIdx.x];
-    if (u >= n_units) return;
-    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t s0 = unit_slot[u], s1 = unit_slot[u + 1];
-    unsigned long long sa = 0, su = 0;
-    for (uint32_t k = s0 + threadIdx.x; k < s1; k += FB) {
-        const uint32_t aa = u32[L.a_all + k], au = u32[L.a_uniq + k];
-        p32[k] = aa - u32[L.b_all + k];
-        p32[(size_t)n_slots + k] = au - u32[L.b_uniq + k];
-        sa += aa;
-        su += au;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        sa += __shfl_down(sa, o, 64);
-        su += __shfl_down(su, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&s_sum[0], sa);
-        atomicAdd(&s_sum[1], su);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        p64[16 + u] = s_sum[0];
-        p64[16 + (size_t)n_units + u] = s_sum[1];
-    }
 }
 
 __global__ __launch_bounds__(FB) void k_finish_unit(const uint32_t *__restrict__ unit_slot, const uint4 *__restrict__ unit_ids,
@@ -132,9 +98,12 @@ int itx_launch_export(const itx_table *t, int mode, const uint64_t *u64, const u
                       uint32_t *p32, hipStream_t st)
 {
     if (mode == ITX_MODE_STAT) {
-        const uint32_t g = t->n_units ? t->n_units : 1;
-        hipLaunchKernelGGL(k_export_unit, dim3(g), dim3(FB), 0, st, t->d_unit_slot, u64, u32, L, t->n_units, t->n_slots, p64, p32);
-        ITX_HIP(hipGetLastError());
+        // the accumulators are kept in the partial's own form: the counters as they are, the two D arrays without their padding
+        ITX_HIP(hipMemcpyAsync(p64, u64, (16 + 2 * (size_t)t->n_units) * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        if (t->n_slots) {
+            ITX_HIP(hipMemcpyAsync(p32, u32 + L.d_all, (size_t)t->n_slots * 4, hipMemcpyDeviceToDevice, st));
+            ITX_HIP(hipMemcpyAsync(p32 + t->n_slots, u32 + L.d_uniq, (size_t)t->n_slots * 4, hipMemcpyDeviceToDevice, st));
+        }
     } else {
         ITX_HIP(hipMemsetAsync(p64, 0, (16 + 2 * (size_t)t->n_units) * sizeof(uint64_t), st));
         ITX_HIP(hipMemcpyAsync(p64, u64, 16 * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));

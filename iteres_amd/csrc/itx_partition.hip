@@ -19,10 +19,11 @@
 //   P  k_scatter   per region: cursor[p] = base[p][sub] + offset row in LDS, then every run of equal partitions
 //                  takes its places with one returning LDS add and writes its keys, now 4 bytes each (slot within
 //                  the partition << 16 | low half of the 8-byte key) — no global atomics.
-//   H  k_hist      per item: LDS window of the partition's W slots (A|B counts, all:16|uniq:16 packed),
-//                  ds_add per key, then the window is added into the global A/B arrays — plain
-//                  coalesced read-modify-write when the item owns its partition, atomics (few: the
-//                  partition is hot, so many keys share a slot) when it is one of several.
+//   H  k_hist      per item: LDS window of the partition's W slots (start | end marks, all:16|uniq:16 packed),
+//                  ds_add per key; reads per unit = sums of the start marks over each unit's slots (few u64 atomics);
+//                  then D = starts - ends is added into the two global arrays — plain coalesced read-modify-write
+//                  when the item owns its partition, atomics (few: the partition is hot, so many keys share a
+//                  slot) when it is one of several.
 //
 // Integer sums only: the result is independent of order, identical to the atomic path and the oracle.
 #include "itx_partition.h"
@@ -32,7 +33,6 @@
 
 #define PB 256              // threads per workgroup (count / scatter)
 #define HB 1024             // threads per workgroup (hist): 2 workgroups per CU keep 32 waves in flight
-#define ITX_LOGW 13         // slots per partition (W = 8192): LDS window of k_hist = W * 8 bytes = 64 KiB
 #define ITX_W (1u << ITX_LOGW)
 #define ITX_CHUNK 65535u    // max keys per k_hist item: keeps the packed 16-bit halves from overflowing
 #define ITX_MAXP 4096u      // partitions the LDS histograms / the plan kernel are sized for
@@ -205,8 +205,9 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0,
 
 // ------------------------------------------------------------------------------------------------ H
 __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1, const uint4 *__restrict__ items,
-                                             const uint32_t *__restrict__ n_items, uint32_t *__restrict__ u32, ItxAccumLayout L,
-                                             uint32_t n_slots)
+                                             const uint32_t *__restrict__ n_items, uint32_t *__restrict__ u32, uint64_t *__restrict__ u64,
+                                             ItxAccumLayout L, uint32_t n_slots, const uint32_t *__restrict__ unit_slot,
+                                             const uint32_t *__restrict__ part_unit)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_a[ITX_W], s_b[ITX_W];   // packed all:16 | uniq:16
     const uint32_t nI = *n_items;
@@ -238,52 +239,55 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
         __syncthreads();
         uint32_t lim = n_slots - slot0;
         if (lim > ITX_W) lim = ITX_W;
+        // reads per unit: every classified read left exactly one start mark inside its unit's slots (in the unit's extra
+        // slot when it adds no coverage); waves take the units that reach into this window in turn
+        {
+            const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+            for (uint32_t u = part_unit[item.x] + wave; u < (uint32_t)L.n_units; u += HB / 64) {
+                const uint32_t us = unit_slot[u], ue = unit_slot[u + 1];
+                if (us >= slot0 + lim) break;
+                const uint32_t lo = us > slot0 ? us - slot0 : 0u, hi = ue < slot0 + lim ? ue - slot0 : lim;
+                uint32_t acc = 0;                                 // packed all:16 | uniq:16; an item holds <= 65535 keys
+                for (uint32_t k = lo + lane; k < hi; k += 64) acc += s_a[k];
+                for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_down((int32_t)acc, o, 64);
+                if (lane == 0 && acc) {
+                    atomicAdd((unsigned long long *)&u64[16 + u], (unsigned long long)(acc & 0xffffu));
+                    if (acc >> 16) atomicAdd((unsigned long long *)&u64[16 + L.n_units + u], (unsigned long long)(acc >> 16));
+                }
+            }
+        }
         if (item.w) {
-            // this item owns the partition: plain read-modify-write, 4 consecutive slots per thread (16-byte accesses;
-            // the arrays start 256-byte aligned and slot0 is a multiple of the window)
+            // this item owns the partition: plain read-modify-write of D = starts - ends, 4 consecutive slots per thread
+            // (16-byte accesses; the arrays start 256-byte aligned and slot0 is a multiple of the window)
             for (uint32_t k = 4 * threadIdx.x; k < ITX_W; k += 4 * HB) {
                 const uint4 a = *reinterpret_cast<const uint4 *>(&s_a[k]);
                 const uint4 b = *reinterpret_cast<const uint4 *>(&s_b[k]);
-                const bool anya = (a.x | a.y | a.z | a.w) != 0, anyb = (b.x | b.y | b.z | b.w) != 0;
-                if (!(anya || anyb)) continue;
+                // per slot: low half all reads, high half unique reads; the differences wrap mod 2^32 like the counters
+                const uint4 da = make_uint4((a.x & 0xffffu) - (b.x & 0xffffu), (a.y & 0xffffu) - (b.y & 0xffffu), (a.z & 0xffffu) - (b.z & 0xffffu),
+                                            (a.w & 0xffffu) - (b.w & 0xffffu));
+                const uint4 du = make_uint4((a.x >> 16) - (b.x >> 16), (a.y >> 16) - (b.y >> 16), (a.z >> 16) - (b.z >> 16), (a.w >> 16) - (b.w >> 16));
+                const bool anya = (da.x | da.y | da.z | da.w) != 0, anyu = (du.x | du.y | du.z | du.w) != 0;
+                if (!(anya || anyu)) continue;
                 const size_t g = (size_t)slot0 + k;
                 if (k + 4 <= lim) {
-                    // the (up to) four 16-byte loads go out together, then the adds and the stores
-                    const bool ua = (a.x | a.y | a.z | a.w) >> 16, ub = (b.x | b.y | b.z | b.w) >> 16;
-                    uint4 xa = make_uint4(0, 0, 0, 0), ya = xa, xb = xa, yb = xa;
-                    if (anya) xa = *reinterpret_cast<const uint4 *>(&u32[L.a_all + g]);
-                    if (ua) ya = *reinterpret_cast<const uint4 *>(&u32[L.a_uniq + g]);
-                    if (anyb) xb = *reinterpret_cast<const uint4 *>(&u32[L.b_all + g]);
-                    if (ub) yb = *reinterpret_cast<const uint4 *>(&u32[L.b_uniq + g]);
+                    uint4 xa = make_uint4(0, 0, 0, 0), xu = xa;
+                    if (anya) xa = *reinterpret_cast<const uint4 *>(&u32[L.d_all + g]);
+                    if (anyu) xu = *reinterpret_cast<const uint4 *>(&u32[L.d_uniq + g]);
                     if (anya) {
-                        xa.x += a.x & 0xffffu; xa.y += a.y & 0xffffu; xa.z += a.z & 0xffffu; xa.w += a.w & 0xffffu;
-                        *reinterpret_cast<uint4 *>(&u32[L.a_all + g]) = xa;
+                        xa.x += da.x; xa.y += da.y; xa.z += da.z; xa.w += da.w;
+                        *reinterpret_cast<uint4 *>(&u32[L.d_all + g]) = xa;
                     }
-                    if (ua) {
-                        ya.x += a.x >> 16; ya.y += a.y >> 16; ya.z += a.z >> 16; ya.w += a.w >> 16;
-                        *reinterpret_cast<uint4 *>(&u32[L.a_uniq + g]) = ya;
-                    }
-                    if (anyb) {
-                        xb.x += b.x & 0xffffu; xb.y += b.y & 0xffffu; xb.z += b.z & 0xffffu; xb.w += b.w & 0xffffu;
-                        *reinterpret_cast<uint4 *>(&u32[L.b_all + g]) = xb;
-                    }
-                    if (ub) {
-                        yb.x += b.x >> 16; yb.y += b.y >> 16; yb.z += b.z >> 16; yb.w += b.w >> 16;
-                        *reinterpret_cast<uint4 *>(&u32[L.b_uniq + g]) = yb;
+                    if (anyu) {
+                        xu.x += du.x; xu.y += du.y; xu.z += du.z; xu.w += du.w;
+                        *reinterpret_cast<uint4 *>(&u32[L.d_uniq + g]) = xu;
                     }
                 } else {                                         // the last, partial group of the slot space
-                    const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+                    const uint32_t av[4] = {da.x, da.y, da.z, da.w}, uv[4] = {du.x, du.y, du.z, du.w};
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         if (k + i < lim) {
-                            if (av[i]) {
-                                u32[L.a_all + g + i] += av[i] & 0xffffu;
-                                u32[L.a_uniq + g + i] += av[i] >> 16;
-                            }
-                            if (bv[i]) {
-                                u32[L.b_all + g + i] += bv[i] & 0xffffu;
-                                u32[L.b_uniq + g + i] += bv[i] >> 16;
-                            }
+                            if (av[i]) u32[L.d_all + g + i] += av[i];
+                            if (uv[i]) u32[L.d_uniq + g + i] += uv[i];
                         }
                     }
                 }
@@ -293,14 +297,9 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
             // lane-contiguous so that a wave's adds fall into as few 64-byte requests as possible
             for (uint32_t k = threadIdx.x; k < lim; k += HB) {
                 const uint32_t a = s_a[k], b = s_b[k];
-                if (a) {
-                    atomicAdd(&u32[L.a_all + slot0 + k], a & 0xffffu);
-                    if (a >> 16) atomicAdd(&u32[L.a_uniq + slot0 + k], a >> 16);
-                }
-                if (b) {
-                    atomicAdd(&u32[L.b_all + slot0 + k], b & 0xffffu);
-                    if (b >> 16) atomicAdd(&u32[L.b_uniq + slot0 + k], b >> 16);
-                }
+                const uint32_t da = (a & 0xffffu) - (b & 0xffffu), du = (a >> 16) - (b >> 16);
+                if (da) atomicAdd(&u32[L.d_all + slot0 + k], da);
+                if (du) atomicAdd(&u32[L.d_uniq + slot0 + k], du);
             }
         }
         __syncthreads();
@@ -334,7 +333,7 @@ int itx_part_run(ItxPartWork *w, const ItxDevTable &T, const ItxRunParams &P, co
                        w->n_part);
     ITX_HIP(hipGetLastError());
     ITX_HIP(hipEventRecord(ev[3], st));
-    hipLaunchKernelGGL(k_hist, dim3(1024), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, L, T.n_slots);
+    hipLaunchKernelGGL(k_hist, dim3(1024), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, u64, L, T.n_slots, T.unit_slot, T.part_unit);
     ITX_HIP(hipGetLastError());
     ITX_HIP(hipEventRecord(ev[4], st));
     for (int k = 0; k < 5; k++) w->ev.push_back(ev[k]);

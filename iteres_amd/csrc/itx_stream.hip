@@ -517,11 +517,18 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 if (hit[j] >= 0) {
-                    atomicAdd(&u32[L.a_all + sA[j]], 1u);
-                    if (hB[j]) atomicAdd(&u32[L.b_all + sB[j]], 1u);
+                    const uint32_t unit = T.row_unit[hit[j]];
+                    atomicAdd((unsigned long long *)&u64[16 + unit], 1ull);
+                    if (hB[j]) {
+                        atomicAdd(&u32[L.d_all + sA[j]], 1u);
+                        atomicAdd(&u32[L.d_all + sB[j]], 0xffffffffu);              // -1 mod 2^32
+                    }
                     if (uq[j]) {
-                        atomicAdd(&u32[L.a_uniq + sA[j]], 1u);
-                        if (hB[j]) atomicAdd(&u32[L.b_uniq + sB[j]], 1u);
+                        atomicAdd((unsigned long long *)&u64[16 + L.n_units + unit], 1ull);
+                        if (hB[j]) {
+                            atomicAdd(&u32[L.d_uniq + sA[j]], 1u);
+                            atomicAdd(&u32[L.d_uniq + sB[j]], 0xffffffffu);
+                        }
                     }
                 }
             }

@@ -235,6 +235,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     std::vector<uint2> bl(bin_off[n_chrom]);
     std::vector<ItxIv> iv(n_rows);
     std::vector<int32_t> orig(n_rows);
+    std::vector<uint32_t> row_unit(n_rows);
     std::vector<int32_t> csize(n_chrom);
     for_each_chrom(n_chrom, [&](int c) {
         csize[c] = (int32_t)chrom_size[c];
@@ -255,6 +256,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
             d.zslot = unit_slot[u] + len;
             d.rank = rank_of_row[order[k]];
             orig[k] = (int32_t)order[k];
+            row_unit[k] = u;
         }
         uint32_t nb = bin_off[c + 1] - bin_off[c];
         uint32_t k = lo, m = lo;
@@ -277,6 +279,18 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     const size_t o_iv = cv.take((n_rows + 1) * sizeof(ItxIv));
     const size_t o_orig = cv.take((n_rows + 1) * 4);
     const size_t o_bl = cv.take((bl.size() + 1) * sizeof(uint2));
+    // first unit reaching into every window of 2^ITX_LOGW slots (k_hist sums the starts of a window per unit)
+    const size_t n_win = ((size_t)slots >> ITX_LOGW) + 2;
+    std::vector<uint32_t> part_unit(n_win, n_units);
+    {
+        uint32_t u = 0;
+        for (size_t w = 0; w < n_win; w++) {
+            while (u < n_units && (uint64_t)unit_slot[u + 1] <= ((uint64_t)w << ITX_LOGW)) u++;
+            part_unit[w] = u;
+        }
+    }
+    const size_t o_runit = cv.take((n_rows + 1) * 4);
+    const size_t o_punit = cv.take(n_win * 4);
     const size_t o_uslot = cv.take(((size_t)n_units + 1) * 4);
     const size_t o_uids = cv.take(((size_t)n_units + 1) * sizeof(uint4));
     const size_t o_ucov = cv.take(((size_t)n_units + 1) * 8);
@@ -294,6 +308,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     };
     bool ok = up(o_iv, iv.data(), iv.size() * sizeof(ItxIv)) &&
               up(o_orig, orig.data(), orig.size() * 4) && up(o_bl, bl.data(), bl.size() * sizeof(uint2)) &&
+              up(o_runit, row_unit.data(), row_unit.size() * 4) && up(o_punit, part_unit.data(), part_unit.size() * 4) &&
               up(o_uslot, unit_slot.data(), unit_slot.size() * 4) && up(o_uids, unit_ids.data(), unit_ids.size() * sizeof(uint4)) &&
               up(o_ucov, unit_covoff.data(), unit_covoff.size() * 8);
     if (!ok) {
@@ -318,11 +333,16 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     t->dev.iv = (const ItxIv *)(base + o_iv);
     t->dev.orig = (const int32_t *)(base + o_orig);
     t->dev.bl = (const uint2 *)(base + o_bl);
+    t->dev.row_unit = (const uint32_t *)(base + o_runit);
+    t->dev.unit_slot = (const uint32_t *)(base + o_uslot);
+    t->dev.part_unit = (const uint32_t *)(base + o_punit);
     t->dev.shift = shift;
     t->dev.n_rows = (uint32_t)n_rows;
     t->dev.n_units = n_units;
     t->dev.n_slots = (uint32_t)slots;
     t->d_unit_slot = (uint32_t *)(base + o_uslot);
+    t->d_row_unit = (uint32_t *)(base + o_runit);
+    t->d_part_unit = (uint32_t *)(base + o_punit);
     t->d_unit_ids = (uint4 *)(base + o_uids);
     t->d_unit_covoff = (uint64_t *)(base + o_ucov);
     t->h_rep_len = (uint32_t *)malloc(sizeof(uint32_t) * (n_rep + 1));

@@ -79,7 +79,8 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     if (!e) return ITX_E_NOMEM;
     e->t = t;
     e->p = *p;
-    if (e->p.accum == ITX_ACCUM_DEFAULT) e->p.accum = ITX_ACCUM_PARTITION;
+    const bool accum_default = e->p.accum == ITX_ACCUM_DEFAULT;
+    if (accum_default) e->p.accum = ITX_ACCUM_PARTITION;
     if (e->p.mode == ITX_MODE_FILTER) e->p.accum = ITX_ACCUM_ATOMIC;   // per-locus counts: one atomic per run of equal rows
     e->cap = batch_capacity;
     e->L = itx_accum_layout(t->n_slots, t->n_rows, t->n_units);
@@ -110,7 +111,12 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     }
     if (e->p.accum == ITX_ACCUM_PARTITION) {
         int rc = itx_part_create(t, batch_capacity, &e->pw);
-        if (rc != ITX_OK) {
+        if (rc == ITX_E_LIMIT && accum_default) {
+            // a slot space beyond the partition path's window table (> 4096 x 8192 consensus slots): the device atomics
+            // path gives the same sums, slower; only an explicit ITX_ACCUM_PARTITION request fails
+            e->p.accum = ITX_ACCUM_ATOMIC;
+            e->pw = nullptr;
+        } else if (rc != ITX_OK) {
             itx_engine_destroy(e);
             return rc;
         }

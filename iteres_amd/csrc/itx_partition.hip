@@ -14,8 +14,9 @@
 //                  one of 8 sub-cursors (workgroup id mod 8: the dispatcher deals workgroups round-robin over
 //                  the 8 XCDs, so a sub-cursor is mostly hit from one XCD and no address sees more than
 //                  n_blocks/8 adds); the offsets it got are stored as the region's row of an offset matrix.
-//   S  k_plan      one workgroup: exclusive scan of the 8*P sub-totals -> bases, and the work list of
-//                  (partition, key range) items for H (a partition with more than ITX_CHUNK keys is split).
+//   S  (inside P)  exclusive scan of the 8*P sub-totals -> bases, recomputed by every workgroup of k_scatter (a few tens
+//                  of kilobytes out of L2; cheaper than a launch of its own), and the work list of (partition, key
+//                  range) items for H (a partition with more than ITX_CHUNK keys is split), written by workgroup 0.
 //   P  k_scatter   per region: cursor[p] = base[p][sub] + offset row in LDS, then every run of equal partitions
 //                  takes its places with one returning LDS add and writes its keys, now 4 bytes each (slot within
 //                  the partition << 16 | low half of the 8-byte key) — no global atomics.
@@ -46,12 +47,12 @@ struct ItxPartWork {
     uint2 *keys0;              // [2*cap] 8-byte keys as emitted, per workgroup region
     uint32_t *keys1;           // [2*cap] 4-byte keys, partitioned
     uint32_t *blk_cnt;         // [max_blocks][4] keys emitted by each wave of each workgroup (into its quarter of the region)
-    uint32_t *subcur;          // [n_part*8] sub-totals, then (after k_plan) bases
+    uint32_t *subcur;          // [n_part*8] keys reserved per (partition, sub-cursor); zero between batches (k_hist clears it)
     uint32_t *offm;            // [max_blocks][n_part] offset of each region inside (partition, sub)
     uint4    *items;           // [max_items] (partition, begin, end, exclusive)
     uint32_t *n_items;         // [1]
     void *base;
-    std::vector<hipEvent_t> ev;    // 5 events per batch: before stream, after stream, plan, scatter, hist
+    std::vector<hipEvent_t> ev;    // 4 events per batch: before stream, after stream, after scatter, after hist
     uint64_t keys_last;
 };
 
@@ -87,6 +88,12 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
         return ITX_E_NOMEM;
     }
     w->base = base;
+    if (hipMemset(base + o_sc, 0, ((size_t)w->n_part * ITX_SUB + 1) * 4) != hipSuccess) {      // k_hist keeps it zero between batches
+        itx_set_error("partition path: hipMemset failed");
+        (void)hipFree(base);
+        delete w;
+        return ITX_E_NO_DEVICE;
+    }
     w->keys0 = (uint2 *)(base + o_k0);
     w->keys1 = (uint32_t *)(base + o_k1);
     w->blk_cnt = (uint32_t *)(base + o_bc);
@@ -106,64 +113,100 @@ void itx_part_destroy(ItxPartWork *w)
     delete w;
 }
 
-// ------------------------------------------------------------------------------------------------ S
-__global__ __launch_bounds__(1024) void k_plan(uint32_t *__restrict__ subcur, uint32_t n_part, uint4 *__restrict__ items,
-                                               uint32_t *__restrict__ n_items)
+// ------------------------------------------------------------------------------------------------ P
+// Block-wide exclusive prefix sums of two values per thread (PB threads). Returns the exclusive sums; *tot_* = block totals.
+__device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_t *ea, uint32_t *eb, uint32_t *tot_a, uint32_t *tot_b)
 {
-    // n_part <= 4096: each of 1024 threads owns up to 4 consecutive partitions (8 sub-totals each)
-    __shared__ uint32_t s_k[1024], s_i[1024];
-    const uint32_t per = (n_part + 1023) / 1024;
-    const uint32_t p0 = threadIdx.x * per;
-    uint32_t keys = 0, its = 0;
-    for (uint32_t p = p0; p < p0 + per && p < n_part; p++) {
-        uint32_t c = 0;
-        for (uint32_t x = 0; x < ITX_SUB; x++) c += subcur[p * ITX_SUB + x];
-        keys += c;
-        its += (c + ITX_CHUNK - 1) / ITX_CHUNK;
+    __shared__ uint32_t s_wa[PB / 64], s_wb[PB / 64];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ta = (uint32_t)__shfl_up((int32_t)ia, o, 64), tb = (uint32_t)__shfl_up((int32_t)ib, o, 64);
+        if (lane >= (uint32_t)o) {
+            ia += ta;
+            ib += tb;
+        }
     }
-    s_k[threadIdx.x] = keys;
-    s_i[threadIdx.x] = its;
+    if (lane == 63) {
+        s_wa[w] = ia;
+        s_wb[w] = ib;
+    }
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t a = 0, b = 0;
-        if (threadIdx.x >= o) {
-            a = s_k[threadIdx.x - o];
-            b = s_i[threadIdx.x - o];
+    uint32_t oa = 0, ob = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PB / 64; k++) {
+        if (k < w) {
+            oa += s_wa[k];
+            ob += s_wb[k];
         }
-        __syncthreads();
-        s_k[threadIdx.x] += a;
-        s_i[threadIdx.x] += b;
-        __syncthreads();
+        ta += s_wa[k];
+        tb += s_wb[k];
     }
-    uint32_t kb = s_k[threadIdx.x] - keys, ib = s_i[threadIdx.x] - its;   // exclusive
-    for (uint32_t p = p0; p < p0 + per && p < n_part; p++) {
-        const uint32_t pb = kb;
-        for (uint32_t x = 0; x < ITX_SUB; x++) {                          // sub-totals become bases
-            const uint32_t c = subcur[p * ITX_SUB + x];
-            subcur[p * ITX_SUB + x] = kb;
-            kb += c;
-        }
-        const uint32_t c = kb - pb;
-        const uint32_t ni = (c + ITX_CHUNK - 1) / ITX_CHUNK;
-        for (uint32_t j = 0; j < ni; j++) {
-            const uint32_t b = pb + j * ITX_CHUNK;
-            const uint32_t e = (j + 1 == ni) ? pb + c : b + ITX_CHUNK;
-            items[ib + j] = make_uint4(p, b, e, ni == 1 ? 1u : 0u);
-        }
-        ib += ni;
-    }
-    if (threadIdx.x == 1023) *n_items = s_i[1023];
+    *ea = oa + ia - a;
+    *eb = ob + ib - b;
+    *tot_a = ta;
+    *tot_b = tb;
+    __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------ P
 __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0, const uint32_t *__restrict__ blk_cnt, size_t span,
                                                 const uint32_t *__restrict__ subcur, const uint32_t *__restrict__ offm,
-                                                uint32_t *__restrict__ keys1, uint32_t n_part)
+                                                uint32_t *__restrict__ keys1, uint32_t n_part, uint4 *__restrict__ items,
+                                                uint32_t *__restrict__ n_items)
 {
     extern __shared__ uint32_t s_cur[];                       // [n_part] next free place of this region in each partition
     const uint32_t sub = blockIdx.x & (ITX_SUB - 1);
     const uint32_t *row = offm + (size_t)blockIdx.x * n_part;
-    for (uint32_t k = threadIdx.x; k < n_part; k += PB) s_cur[k] = subcur[k * ITX_SUB + sub] + row[k];
+    // The plan, recomputed by every workgroup (8*P sub-totals, a few tens of kilobytes out of L2): partition p starts at
+    // the sum of all smaller partitions' keys, its sub-cursor `sub` behind the sub-totals below it, this region at the
+    // offset it reserved there. Workgroup 0 also writes the work list of k_hist: (partition, key range) items, a
+    // partition with more than ITX_CHUNK keys split.
+    {
+        const uint32_t per = (n_part + PB - 1) / PB;                       // <= ITX_MAXP / PB = 16 partitions per thread
+        const uint32_t p0 = threadIdx.x * per, p1 = p0 + per < n_part ? p0 + per : n_part;
+        uint32_t keys = 0, its = 0, cnt[ITX_MAXP / PB];
+#pragma unroll
+        for (uint32_t i = 0; i < ITX_MAXP / PB; i++) {
+            const uint32_t p = p0 + i;
+            cnt[i] = 0;
+            if (i < per && p < p1) {
+                const uint4 lo = *reinterpret_cast<const uint4 *>(&subcur[p * ITX_SUB]), hi = *reinterpret_cast<const uint4 *>(&subcur[p * ITX_SUB + 4]);
+                const uint32_t v[ITX_SUB] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                uint32_t below = 0, c = 0;
+#pragma unroll
+                for (uint32_t x = 0; x < ITX_SUB; x++) {
+                    below += x < sub ? v[x] : 0u;
+                    c += v[x];
+                }
+                cnt[i] = c;
+                s_cur[p] = below + row[p];
+                keys += c;
+                its += (c + ITX_CHUNK - 1) / ITX_CHUNK;
+            }
+        }
+        uint32_t kb, ib, tk, ti;
+        block_excl_scan2(keys, its, &kb, &ib, &tk, &ti);
+#pragma unroll
+        for (uint32_t i = 0; i < ITX_MAXP / PB; i++) {
+            const uint32_t p = p0 + i;
+            if (i < per && p < p1) {
+                const uint32_t c = cnt[i];
+                s_cur[p] += kb;
+                if (blockIdx.x == 0) {
+                    const uint32_t ni = (c + ITX_CHUNK - 1) / ITX_CHUNK;
+                    for (uint32_t j = 0; j < ni; j++) {
+                        const uint32_t b = kb + j * ITX_CHUNK;
+                        const uint32_t e = (j + 1 == ni) ? kb + c : b + ITX_CHUNK;
+                        items[ib + j] = make_uint4(p, b, e, ni == 1 ? 1u : 0u);
+                    }
+                    ib += ni;
+                }
+                kb += c;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_items = ti;
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     // 8 rounds of 256 keys per iteration: the loads of all eight are in flight before the first is used
@@ -207,9 +250,11 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0,
 __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1, const uint4 *__restrict__ items,
                                              const uint32_t *__restrict__ n_items, uint32_t *__restrict__ u32, uint64_t *__restrict__ u64,
                                              ItxAccumLayout L, uint32_t n_slots, const uint32_t *__restrict__ unit_slot,
-                                             const uint32_t *__restrict__ part_unit)
+                                             const uint32_t *__restrict__ part_unit, uint32_t *__restrict__ subcur, uint32_t n_sub)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_a[ITX_W], s_b[ITX_W];   // packed all:16 | uniq:16
+    // the sub-totals have done their job (k_scatter is through): zero them for the next batch's reservations
+    for (uint32_t i = blockIdx.x * HB + threadIdx.x; i < n_sub; i += gridDim.x * HB) subcur[i] = 0;
     const uint32_t nI = *n_items;
     for (uint32_t it = blockIdx.x; it < nI; it += gridDim.x) {
         const uint4 item = items[it];
@@ -318,37 +363,35 @@ int itx_part_run(ItxPartWork *w, const ItxDevTable &T, const ItxRunParams &P, co
     size_t span = (n + w->max_blocks - 1) / w->max_blocks;
     span = (span + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
     const uint32_t nb = (uint32_t)((n + span - 1) / span);
-    ITX_HIP(hipMemsetAsync(w->subcur, 0, (size_t)w->n_part * ITX_SUB * 4, st));
-    hipEvent_t ev[5];
-    for (int k = 0; k < 5; k++) ITX_HIP(hipEventCreate(&ev[k]));
+    hipEvent_t ev[4];
+    for (int k = 0; k < 4; k++) ITX_HIP(hipEventCreate(&ev[k]));
     ITX_HIP(hipEventRecord(ev[0], st));
     ItxEmitPlan E = {w->subcur, w->offm, w->n_part, ITX_LOGW};
     int rc = itx_launch_stream(ITX_DO_EMIT, T, P, B, n, span, nb, d_hit_row, u64, u32, L, w->keys0, w->blk_cnt, E, st);
     if (rc) return rc;
     ITX_HIP(hipEventRecord(ev[1], st));
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, w->subcur, w->n_part, w->items, w->n_items);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(PB), (size_t)w->n_part * 4, st, w->keys0, w->blk_cnt, span, w->subcur, w->offm, w->keys1,
+                       w->n_part, w->items, w->n_items);
     ITX_HIP(hipGetLastError());
     ITX_HIP(hipEventRecord(ev[2], st));
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(PB), (size_t)w->n_part * 4, st, w->keys0, w->blk_cnt, span, w->subcur, w->offm, w->keys1,
-                       w->n_part);
+    hipLaunchKernelGGL(k_hist, dim3(1024), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, u64, L, T.n_slots, T.unit_slot, T.part_unit,
+                       w->subcur, w->n_part * ITX_SUB);
     ITX_HIP(hipGetLastError());
     ITX_HIP(hipEventRecord(ev[3], st));
-    hipLaunchKernelGGL(k_hist, dim3(1024), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, u64, L, T.n_slots, T.unit_slot, T.part_unit);
-    ITX_HIP(hipGetLastError());
-    ITX_HIP(hipEventRecord(ev[4], st));
-    for (int k = 0; k < 5; k++) w->ev.push_back(ev[k]);
+    for (int k = 0; k < 4; k++) w->ev.push_back(ev[k]);
     return ITX_OK;
 }
 
 void itx_part_fold_stats(ItxPartWork *w, double *ms, uint64_t *keys_last)
 {
-    for (size_t i = 0; i + 5 <= w->ev.size(); i += 5) {
-        if (hipEventSynchronize(w->ev[i + 4]) == hipSuccess)
-            for (int k = 0; k < 4; k++) {
+    static const int stage_of[3] = {0, 2, 3};                 // stream, (the plan is part of the scatter now), scatter, hist
+    for (size_t i = 0; i + 4 <= w->ev.size(); i += 4) {
+        if (hipEventSynchronize(w->ev[i + 3]) == hipSuccess)
+            for (int k = 0; k < 3; k++) {
                 float t = 0;
-                if (hipEventElapsedTime(&t, w->ev[i + k], w->ev[i + k + 1]) == hipSuccess) ms[k] += t;
+                if (hipEventElapsedTime(&t, w->ev[i + k], w->ev[i + k + 1]) == hipSuccess) ms[stage_of[k]] += t;
             }
-        for (int k = 0; k < 5; k++) (void)hipEventDestroy(w->ev[i + k]);
+        for (int k = 0; k < 4; k++) (void)hipEventDestroy(w->ev[i + k]);
     }
     w->ev.clear();
     // keys of the most recent batch = end of the last sub-cursor base + ... : read the plan's item list tail instead

@@ -515,6 +515,9 @@ static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_sid
             for (;;) {
                 size_t p = r->upos;
                 while (p + 4 <= r->ulen) {
+                    /* the hop is a pointer chase through bytes other cores have just written: ask for the lines ahead */
+                    __builtin_prefetch(r->ubuf + p + 1024);
+                    __builtin_prefetch(r->ubuf + p + 2048);
                     const int32_t bl = rd_i32(r->ubuf + p);
                     if (bl < 32) {                                /* bam.c:186-190: a malformed length ends the file */
                         r->eof = 1;

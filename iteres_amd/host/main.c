@@ -29,7 +29,7 @@ int main(int argc, char *argv[])
      * spinning on a shared box cost more than they give */
     if (!getenv("OMP_NUM_THREADS")) {
         int n = omp_get_num_procs();
-        if (n > 32) n = 32;
+        if (n > 16) n = 16;
         omp_set_num_threads(n > 0 ? n : 1);
     }
     if (strcmp(argv[1], "stat") == 0) return main_stat(argc - 1, argv + 1);

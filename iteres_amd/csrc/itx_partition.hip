@@ -72,8 +72,13 @@ int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
     w->max_blocks = itx_stream_blocks(t->device);
     w->max_items = w->n_part + (uint32_t)((2 * cap) / ITX_CHUNK) + 2;
     const size_t kcap = 2 * (cap + ITX_STREAM_TILE) * 4 + 64;
+    // keys as emitted: every workgroup owns the 2 * span slots of its span of records, its four waves a quarter each, so
+    // the slots run to 2 * n_blocks * span — up to one span beyond the records
+    size_t span_cap = (cap + w->max_blocks - 1) / w->max_blocks;
+    span_cap = (span_cap + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
+    const size_t k0cap = 2 * (cap + span_cap + ITX_STREAM_TILE) * 8 + 64;
     size_t off = 0;
-    const size_t o_k0 = off; off = al256(off + 2 * kcap);
+    const size_t o_k0 = off; off = al256(off + k0cap);
     const size_t o_k1 = off; off = al256(off + kcap);
     const size_t o_bc = off; off = al256(off + (size_t)w->max_blocks * 4 * 4);
     const size_t o_sc = off; off = al256(off + ((size_t)w->n_part * ITX_SUB + 1) * 4);

@@ -13,7 +13,7 @@
 //   * every record takes the top of its bin from the index slice (one ds_bpermute) and walks down the LDS
 //     window while the rows below still end past its start (ItxIv.pbelow); the four records of a lane advance
 //     in lockstep, one ds_read_b128 each per step.
-// Tiles that do not fit this picture (mixed chromosomes, > 64 bins or > 128 rows: unsorted or very sparse
+// Tiles that do not fit this picture (mixed chromosomes, > 128 bins or > 128 rows: unsorted or very sparse
 // input) take the per-lane global-memory lookup — slower, same results.
 // The tile body is written predicated (selects, no early exits): the kernel is bound by instruction issue,
 // and nested divergent branches cost more exec-mask bookkeeping than the arithmetic they skip.
@@ -70,11 +70,16 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 }
 
 // Top of a record's candidates as a window entry: the first row starting at or after the end of qe's bin, from
-// the wave's slice of the binned index (lane i holds bin bin_lo + i), relative to the window start.
-__device__ __forceinline__ uint32_t top_entry(uint32_t bsx, int32_t qe, int32_t shift, uint32_t bin_lo, uint32_t lo_w)
+// the wave's slice of the binned index (lane i holds bin bin_lo + i in bsx and, for slices of more than 64 bins —
+// sparser read sets — bin bin_lo + 64 + i in bsx_hi), relative to the window start.
+__device__ __forceinline__ uint32_t top_entry(uint32_t bsx, uint32_t bsx_hi, bool wide, int32_t qe, int32_t shift, uint32_t bin_lo, uint32_t lo_w)
 {
-    const uint32_t b = (((uint32_t)qe >> shift) - bin_lo + 1u) & 63u;
-    const uint32_t h1 = (uint32_t)__shfl((int32_t)bsx, (int)b, 64);
+    const uint32_t b = (((uint32_t)qe >> shift) - bin_lo + 1u) & 127u;
+    uint32_t h1 = (uint32_t)__shfl((int32_t)bsx, (int)(b & 63u), 64);
+    if (wide) {                                                    // wave-uniform
+        const uint32_t h2 = (uint32_t)__shfl((int32_t)bsx_hi, (int)(b & 63u), 64);
+        h1 = b >= 64u ? h2 : h1;
+    }
     return __builtin_elementwise_sub_sat(h1, lo_w);
 }
 
@@ -349,11 +354,15 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             mx = wave_max_i32(mx);
             const uint32_t bin_lo = (uint32_t)mn >> T.shift;
             const uint32_t nb = ((uint32_t)mx >> T.shift) + 1 - bin_lo + 1;         // bins bin_lo .. bin(mx)+1
-            bool fast = nb <= 64;
+            bool fast = nb <= 128;
+            const bool wide = nb > 64;                                              // wave-uniform
+            uint32_t bsx_hi = 0;
             if (fast) {
                 if (lane < nb) bs = T.bl[cur_bb + bin_lo + lane];
+                if (wide && lane + 64 < nb) bsx_hi = T.bl[cur_bb + bin_lo + 64 + lane].x;
                 lo_w = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)bs.y);
-                const uint32_t hi_w = (uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, (int)(nb - 1));
+                const uint32_t hi_w = wide ? (uint32_t)__builtin_amdgcn_readlane((int32_t)bsx_hi, (int)(nb - 65))
+                                           : (uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, (int)(nb - 1));
                 wn = hi_w > lo_w ? hi_w - lo_w : 0u;
                 fast = wn <= ITX_WIN;
             }
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                     uint32_t f_rk[RPL];               // FIRST: smallest list-order rank among the hits so far (hk = its entry)
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        const uint32_t top = top_entry(bs.x, qe[j], T.shift, bin_lo, lo_w);   // a shuffle: every lane takes part
+                        const uint32_t top = top_entry(bs.x, bsx_hi, wide, qe[j], T.shift, bin_lo, lo_w);   // a shuffle: every lane takes part
                         kk[j] = q[j] ? top : 0u;                  // rows [0, top) <=> entries [1, top]
                         hk[j] = 0;
                         f_rk[j] = 0xffffffffu;
@@ -431,9 +440,12 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                     }
                     if (__ballot(anyrare)) {
                         IvLds A{win + 2};
-                        uint32_t tops[RPL];
+                        uint32_t tops[RPL];                       // from the index in memory: the slice registers are long dead
 #pragma unroll
-                        for (int j = 0; j < RPL; j++) tops[j] = top_entry(bs.x, qe[j], T.shift, bin_lo, lo_w);   // every lane takes part
+                        for (int j = 0; j < RPL; j++)
+                            tops[j] = (hk[j] != 0 && (hk[j] >= 0x10000u || (uint32_t)qe[j] - (uint32_t)qs[j] >= (1u << 23)))
+                                          ? __builtin_elementwise_sub_sat(T.bl[cur_bb + ((uint32_t)qe[j] >> T.shift) + 1].x, lo_w)
+                                          : 0u;
 #pragma unroll
                         for (int j = 0; j < RPL; j++) {
                             const uint32_t qlen = (uint32_t)qe[j] - (uint32_t)qs[j];

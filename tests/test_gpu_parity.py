@@ -241,6 +241,17 @@ def test_unit_and_window_shapes(accum):
         ec.assert_same(eres, ores, hits, False, n)
 
 
+def test_long_spans_few_workgroups(monkeypatch):
+    """Few workgroups with long spans (ITX_STREAM_BLOCKS): the last workgroup's span is mostly empty, its waves still
+    write their keys into their own quarters of the region — the key buffer has to reach that far."""
+    chroms = [("c1", 20_000_000)]
+    rows, cs, rl, nf, nc, t2c, rd = _synth_case(55, 40_000, 100_000, chroms)
+    for blocks, cap in (("8", 100_000), ("3", 100_000), ("8", 33_333)):
+        monkeypatch.setenv("ITX_STREAM_BLOCKS", blocks)
+        eres, ores, hits = ec.run_both(rows, cs, rl, nf, nc, dict(), t2c, rd, batch_capacity=cap, accum=eng.ACCUM_PARTITION)
+        ec.assert_same(eres, ores, hits, False, len(rows))
+
+
 def test_properties_at_scale():
     """2 M reads vs 300 k rows: results must not depend on how the stream is cut into batches, on record order,
     or on the accumulate path (all sums are integer and commutative)."""

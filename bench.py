@@ -10,7 +10,8 @@ Workload (BASELINE.json configs[1]): a coordinate-sorted 50 M-read synthetic hg3
 resident in HBM when the timed region starts. One "step" = one pass of the hot path over the batch:
 classify + key emit (k_stream) -> radix partition (k_scatter) -> LDS histograms into the device accumulators (k_hist). Weak scaling: every rank owns
 its own 50 M-read shard and a replica of the table; the single end-of-stream exchange — export of the compact
-partial and one RCCL all-reduce (sum) of it — is INSIDE the timed region, after the K steps.
+partial and one RCCL sum-reduce of it onto rank 0 (the rank that would write the files) — is INSIDE the timed region,
+after the K steps.
 
 One JSON line on rank 0. `roofline` is for the dominant kernel (k_stream: derive + classify + key emit), timed
 with HIP events recorded on the submitting stream around that launch, every step of the timed region.
@@ -102,7 +103,7 @@ def main():
     for _ in range(a.steps):
         e.submit_device(ptrs, a.reads, stream=stream)
     e.export_partial(p64.data_ptr(), p32.data_ptr(), stream=stream)
-    idist.allreduce_sum_([p64, p32], dist)          # the one exchange: RCCL sum over xGMI (no-op at N = 1)
+    idist.reduce_sum_([p64, p32], dist, dst=0)      # the one exchange: RCCL sum-reduce over xGMI onto the writing rank (no-op at N = 1)
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
@@ -147,7 +148,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 50M-read coordinate-sorted synthetic hg38 alignments vs 5.5M-row rmsk, iteres stat defaults, per-base coverage on",
                        "reads_per_gpu_per_step": a.reads, "rmsk_rows": int(table.info.n_rows), "rep_names": len(rep_len),
                        "consensus_slots": int(table.info.n_slots), "accumulate": "partition" if a.accum in (0, 2) else "atomic",
-                       "exchange": "1 RCCL all-reduce of the partial after the last step (inside the timed region)" if world > 1 else "partial export only (N=1)"},
+                       "exchange": "1 RCCL sum-reduce of the partial onto rank 0 after the last step (inside the timed region)" if world > 1 else "partial export only (N=1)"},
             "roofline": {"bound": "hbm", "kernel": "k_stream<EMIT> (derive + classify + key emit + partition count)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "avg_launch_ms": round(stream_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),

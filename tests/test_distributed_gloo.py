@@ -61,14 +61,19 @@ def _rank(rank, world, port, q):
     r["cnt"][12] += np.uint64(0xFFFFFFFFFFFFFF00)
     keys = ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq")
     tens = [torch.from_numpy(idist.as_signed_view(r[k])) for k in keys]
-    idist.allreduce_sum_(tens, dist)
+    if os.environ.get("ITX_TEST_EXCHANGE") == "reduce":
+        idist.reduce_sum_(tens, dist, dst=0)            # what bench.py does: only the writing rank gets the sums
+    else:
+        idist.allreduce_sum_(tens, dist)
     if rank == 0:
         q.put({k: r[k].copy() for k in keys} | {"bounds": (lo, hi)})
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange_equals_single_process():
+@pytest.mark.parametrize("exchange", ["allreduce", "reduce"])
+def test_two_rank_exchange_equals_single_process(exchange, monkeypatch):
+    monkeypatch.setenv("ITX_TEST_EXCHANGE", exchange)      # inherited by the spawned ranks
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

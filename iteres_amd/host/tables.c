@@ -22,7 +22,11 @@ void die(const char *fmt, ...)
     vfprintf(stderr, fmt, ap);
     va_end(ap);
     fputc('\n', stderr);
-    exit(-1);
+    /* errAbort ends with exit(-1) (errabort.c:166-172): status 255. Here other threads may be busy (OpenMP workers, the
+     * loader, the HIP runtime starting up on the warm-up thread) and exit()'s teardown would race with them: flush what
+     * stdio holds and leave at once with the same status. */
+    fflush(NULL);
+    _exit(255);
 }
 
 void warnf(const char *fmt, ...)

@@ -336,9 +336,27 @@ def case_cpg():
     emit_case("cpg", t, None, runs, bam=False, sam=False, extra_files={"cpg.bedGraph": bed})
 
 
+def case_addchr():
+    """-C (generic.c:781-791): header names without the "chr" prefix get it, "MT" becomes chrM, "GL*" references are
+    skipped before the unknown-chromosome test, names that already start with "chr" stay; without -C none of the short
+    names is in the size file (one warning each)."""
+    chroms = [("chr1", 900000), ("chr2", 500000), ("chrM", 16571), ("chrX", 300000)]
+    t = synth.make_table(501, chroms, 3000, n_names=150, n_fams=20, n_clas=7, overlap_frac=0.05)
+    header = [("1", 900000), ("2", 500000), ("MT", 16571), ("chrX", 300000), ("GL000191.1", 106433), ("mt", 16571), ("HSCHR6_MHC", 50000)]
+    r = synth.make_reads(502, header, 12000, read_len=(40, 110), paired_frac=0.25, odd_cigar_frac=0.05)
+    runs = [
+        ("stat_C", "stat", ["-w", "-C"], "reads.bam"),
+        ("stat_C_sam", "stat", ["-w", "-C", "-S"], "reads.sam"),
+        ("stat_noC", "stat", ["-w"], "reads.bam"),
+        ("filter_C", "filter", ["-C", "-r"], "reads.bam"),
+        ("stat_C_R_B", "stat", ["-w", "-C", "-R", "-B", "-V"], "reads.bam"),
+    ]
+    emit_case("addchr", t, r, runs)
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -C oracle ref")
-    which = sys.argv[1:] or ["quirks", "mid", "manynames", "cfg1", "sidechan", "cpg"]
+    which = sys.argv[1:] or ["quirks", "mid", "manynames", "cfg1", "sidechan", "cpg", "addchr"]
     for w in which:
         globals()["case_" + w]()

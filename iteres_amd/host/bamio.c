@@ -7,6 +7,7 @@
 #include "itx_host.h"
 
 #include <ctype.h>
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -84,8 +85,34 @@ static int bgzf_header_ok(const uint8_t *h)
            (h[14] | h[15] << 8) == 2;
 }
 
+/* Raw DEFLATE of one block. libdeflate, when the system has it (dlopen, no build-time dependency), inflates two to three
+ * times faster than zlib's inflate(); both are lossless decoders of the same stream, so the bytes are the same.
+ * ITX_NO_LIBDEFLATE=1 keeps zlib. */
+typedef struct libdeflate_decompressor ld_dec;
+static ld_dec *(*ld_alloc)(void);
+static int (*ld_inflate)(ld_dec *, const void *, size_t, void *, size_t, size_t *);
+static int ld_state;                         /* 0 not probed, 1 in use, -1 unavailable */
+static void ld_probe(void)
+{
+    if (ld_state) return;
+    ld_state = -1;
+    if (getenv("ITX_NO_LIBDEFLATE")) return;
+    void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    ld_alloc = (ld_dec * (*)(void)) dlsym(h, "libdeflate_alloc_decompressor");
+    ld_inflate = (int (*)(ld_dec *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+    if (ld_alloc && ld_inflate) ld_state = 1;
+}
+
 static int inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t usize)
 {
+    if (ld_state == 1) {
+        static __thread ld_dec *d;
+        if (!d) d = ld_alloc();
+        size_t got = 0;
+        if (d && ld_inflate(d, src + 18, csize - 18 - 8, dst, usize, &got) == 0 && got == usize) return 0;
+        /* anything unexpected: let zlib have the last word */
+    }
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     zs.next_in = (Bytef *)(src + 18);
@@ -366,6 +393,7 @@ aln_reader *aln_open(const char *path, int is_sam)
 {
     FILE *f = fopen(path, is_sam ? "r" : "rb");
     if (!f) return NULL;
+    ld_probe();
     aln_reader *r = xcalloc(1, sizeof *r);
     r->f = f;
     r->is_sam = is_sam;
@@ -389,7 +417,8 @@ void aln_close(aln_reader *r)
 {
     if (!r) return;
     if (getenv("ITX_TIMING") && !r->is_sam)
-        fprintf(stderr, "[itx timing] BAM decode so far: file read %.3f s, inflate %.3f s, record hop %.3f s, parse %.3f s\n", t_io, t_inflate, t_hop, t_parse);
+        fprintf(stderr, "[itx timing] BAM decode so far: file read %.3f s, inflate (%s) %.3f s, record hop %.3f s, parse %.3f s\n", t_io,
+                ld_state == 1 ? "libdeflate" : "zlib", t_inflate, t_hop, t_parse);
     if (r->pf_on) {
         pthread_mutex_lock(&r->pf_mu);
         while (r->pf_state == 1) pthread_cond_wait(&r->pf_cv, &r->pf_mu);      /* let a chunk in flight land */

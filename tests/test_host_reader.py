@@ -19,7 +19,7 @@ HOST = os.path.join(ROOT, "iteres_amd", "host")
 def dump(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("bin") / "reader_dump")
     subprocess.check_call(["gcc", "-O2", "-g", "-fopenmp", "-std=gnu11", "-o", exe, os.path.join(HOST, "test", "reader_dump.c"),
-                           os.path.join(HOST, "bamio.c"), os.path.join(HOST, "tables.c"), "-lz"])
+                           os.path.join(HOST, "bamio.c"), os.path.join(HOST, "tables.c"), "-lz", "-ldl"])
     return exe
 
 

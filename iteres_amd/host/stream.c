@@ -29,7 +29,12 @@ static int warm_on;
 static void *warm_main(void *arg)
 {
     (void)arg;
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
     (void)itx_device_count();
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    if (getenv("ITX_TIMING"))
+        fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s (helper thread)\n", (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec));
     return NULL;
 }
 void gpu_warmup_start(void)
@@ -110,7 +115,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
 {
     const int timing = getenv("ITX_TIMING") != NULL;
     struct timespec ts0, ts1;
+    const double t_join = now_s();
     gpu_warmup_join();
+    if (timing) fprintf(stderr, "[itx timing] waited %.3f s for the HIP runtime to come up\n", now_s() - t_join);
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     int ndev = itx_device_count();
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
@@ -196,7 +203,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     names_init(&warned);
     for (int fi = 0; fi < n_files; fi++) {
         if (multi_file) fprintf(stderr, "\n* Processing %s\n", files[fi]);
+        const double t_open0 = now_s();
         aln_reader *rd = aln_open(files[fi], o->is_sam);
+        const double t_opened = now_s();
         if (!rd) {
             fprintf(stderr, "Fail to open %s file %s\n", o->is_sam ? "SAM" : "BAM", o->aln_arg);
             die("Error\n");
@@ -334,6 +343,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             pend[s] = n;
             s ^= 1;
         }
+        const double t_loop_done = now_s();
         /* drain both slots before the tid map of the next file replaces this one */
         for (int k = 0; k < 2; k++) {
             chk(itx_engine_wait_slot(eng, k), "itx_engine_wait_slot");
@@ -351,7 +361,11 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         free(t2name);
         free(t2id);
         free(t2c);
+        const double t_drained = now_s();
         aln_close(rd);
+        if (timing)
+            fprintf(stderr, "[itx timing] open %.3f s, record loop %.3f s, drain %.3f s, close %.3f s\n", t_opened - t_open0, t_loop_done - t_opened,
+                    t_drained - t_loop_done, now_s() - t_drained);
     }
     names_free(&warned);
     names_free(&chr_names);

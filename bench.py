@@ -124,6 +124,20 @@ def main():
 
     out = None
     if rank == 0:
+        # what a plain device copy reaches on THIS card (quote the attainable figure beside the 8 TB/s
+        # spec): 1 GiB in + 1 GiB out, best of 5, after the timed region
+        src = torch.empty(1 << 28, dtype=torch.int32, device=dev).fill_(1)
+        dst = torch.empty_like(src)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        copy_ms = []
+        for _ in range(6):
+            ev[0].record()
+            dst.copy_(src)
+            ev[1].record()
+            torch.cuda.synchronize()
+            copy_ms.append(ev[0].elapsed_time(ev[1]))
+        copy_gbs = 2 * src.numel() * 4 / (min(copy_ms[1:]) * 1e-3) / 1e9
+        del src, dst
         ms_per_step = elapsed * 1e3 / a.steps
         value = total_reads / elapsed / 1e6
         stream_ms = st["stage_ms"][0] / max(st["submits"], 1)
@@ -151,7 +165,8 @@ def main():
                        "exchange": "1 RCCL sum-reduce of the partial onto rank 0 after the last step (inside the timed region)" if world > 1 else "partial export only (N=1)"},
             "roofline": {"bound": "hbm", "kernel": "k_stream<EMIT> (derive + classify + key emit + partition count)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "avg_launch_ms": round(stream_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "traffic": traffic, "copy_kernel_GBps": round(copy_gbs, 1), "frac_of_copy_kernel": round(achieved / copy_gbs, 4),
+                         "avg_launch_ms": round(stream_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                          "stage_ms_per_step": {k: round(v / max(st["submits"], 1), 4)
                                                for k, v in zip(("stream", None, "scatter", "hist"), st["stage_ms"]) if k}},
             "checks": checks,
@@ -171,6 +186,25 @@ def main():
         cpu_s = time.perf_counter() - t2
         out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "M alignments/s", "cores": 1, "kind": "port",
                                "sample": f"first {m} records of the same batch, oracle/liboracle.so (single-threaded C restatement of generic.c:745-1036), {cpu_s:.1f} s"}
+        # the same restatement on every host core the box gives us (the reference itself cannot do this: one thread, process
+        # globals): contiguous shards of the sample, private accumulators per thread, read-only table shared
+        nthr = max(1, min(len(os.sched_getaffinity(0)), 16))
+        if nthr > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            mm = min(a.reads, m * 4)
+            cuts = [idist.shard_bounds(mm, t, nthr) for t in range(nthr)]
+            fl_all = np.where(f5[:mm] & 8, 16, 0).astype(np.uint16)
+
+            def one(b):
+                lo, hi = b
+                return ot.run({}, list(range(len(chroms))), tid[lo:hi], pos[lo:hi], tmpend[lo:hi], mapq[lo:hi], fl_all[lo:hi], want_hits=False)["cnt"]
+            t3 = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                parts = list(ex.map(one, cuts))
+            mt_s = time.perf_counter() - t3
+            assert int(sum(int(c[0]) for c in parts)) == mm
+            out["cpu_baseline_mt"] = {"value": round(mm / mt_s / 1e6, 4), "unit": "M alignments/s", "cores": nthr, "kind": "port",
+                                      "sample": f"first {mm} records in {nthr} contiguous shards, one oracle thread each (private accumulators, merge not timed), {mt_s:.1f} s"}
         if a.verify:
             # the same sample through the GPU path must give the oracle's numbers exactly
             e.reset()

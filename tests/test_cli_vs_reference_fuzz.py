@@ -1,0 +1,156 @@
+"""Differential test on the GPU box: the drop-in `iteres` (iteres_amd/host + the HIP engine) against the reference
+binary itself (oracle/_ref/iteres, built from /root/reference by oracle/Makefile; it travels to the GPU box as a built
+file) on seeded random tables, reads and OPTION SETS — every file either program writes must be byte-identical
+(bigWig: same decoded content, tests/refio.py). The committed golden cases pin chosen corners; this sweeps the
+combinations nobody chose. Skipped where the reference binary is absent."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import refio
+from iteres_amd import build, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "iteres")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/iteres not built (make -C oracle ref)")
+    lib, exe = build.build_all()
+    assert exe and os.path.exists(exe)
+    return exe
+
+
+def _xa_aux(rng, r, t, chroms, frac):
+    names = [nm for nm, _ in chroms]
+    aux = [[] for _ in range(len(r))]
+    for i in np.flatnonzero(rng.random(len(r)) < frac):
+        alts = []
+        for _ in range(int(rng.integers(1, 4))):
+            if rng.random() < 0.7:
+                row = int(rng.integers(0, len(t.start)))
+                c, p0 = names[int(t.chrom[row])], int(t.start[row]) + int(rng.integers(-20, 40))
+            else:
+                ci = int(rng.integers(0, len(chroms)))
+                c, p0 = names[ci], int(rng.integers(1, chroms[ci][1]))
+            alts.append(f"{c},{'+' if rng.random() < 0.5 else '-'}{max(p0, 1)},{int(r.l_qseq[i])}M,{int(rng.integers(0, 4))}")
+        fields = [f"XA:Z:{';'.join(alts)};"]
+        if rng.random() < 0.9:
+            fields.insert(0, f"NM:i:{int(rng.integers(0, 4))}")
+        aux[i] = fields
+    return aux
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    chroms = [("chr1", int(rng.integers(300_000, 3_000_000))), ("chr2", int(rng.integers(150_000, 900_000))), ("chrM", 16_571)][: int(rng.integers(1, 4))]
+    t = synth.make_table(seed * 3 + 1, chroms, int(rng.integers(300, 6000)), n_names=int(rng.integers(5, 300)), n_fams=int(rng.integers(2, 30)),
+                         n_clas=int(rng.integers(1, 9)), overlap_frac=float(rng.choice([0.0, 0.03, 0.3])), shuffle_frac=float(rng.choice([0.0, 0.05, 1.0])),
+                         inconsistent_frac=float(rng.choice([0.0, 0.05])), median_len=float(rng.choice([60.0, 200.0, 900.0])))
+    header = list(chroms) + ([("chrUn", 40_000)] if rng.random() < 0.5 else [])
+    r = synth.make_reads(seed * 3 + 2, header, int(rng.integers(200, 30_000)), read_len=(20, int(rng.integers(40, 260))),
+                         paired_frac=float(rng.choice([0.0, 0.3, 1.0])), unmapped_frac=float(rng.choice([0.0, 0.05])),
+                         odd_cigar_frac=float(rng.choice([0.0, 0.2])), sorted_=bool(rng.random() < 0.7))
+    if rng.random() < 0.5:
+        r.aux = _xa_aux(rng, r, t, chroms, float(rng.choice([0.02, 0.4])))
+    if rng.random() < 0.5:                       # exact duplicates for -R
+        for i in rng.choice(np.arange(1, len(r)), max(len(r) // 8, 1), replace=False):
+            for arr in (r.tid, r.pos, r.flag, r.l_qseq, r.mtid, r.mpos, r.isize):
+                arr[i] = arr[i - 1]
+            r.cigars[i] = list(r.cigars[i - 1])
+    r.mapq[:4] = 60                              # -R reads its key buffer before writing it otherwise (uninitialised in the reference)
+    r.flag[:4] &= ~np.uint16(4)
+    return rng, chroms, t, r
+
+
+def _random_opts(rng, t):
+    pick = lambda *a: a[int(rng.integers(0, len(a)))]
+    common = []
+    if rng.random() < 0.5:
+        common += ["-Q", str(pick(0, 1, 20, 37, 61))]
+    if rng.random() < 0.3:
+        common += ["-R"]
+    if rng.random() < 0.3:
+        common += ["-T"]
+    if rng.random() < 0.3:
+        common += ["-D"]
+    if rng.random() < 0.5:
+        common += ["-E", str(pick(0, 1, 50, 150, 400))]
+    if rng.random() < 0.4:
+        common += ["-I", str(pick(100, 350, 1000))]
+    if rng.random() < 0.5:
+        common += ["-N", str(pick(0, 2, 3))]
+    runs = []
+    st = list(common) + ["-w"]
+    if rng.random() < 0.4:
+        st += ["-c", pick("0.3", "0.5", "0.9", "1", "0.0001", "0")]
+    if rng.random() < 0.3:
+        st += ["-x"]
+    if rng.random() < 0.4:
+        st += ["-U", str(pick(0, 1, 2))]
+    if rng.random() < 0.3:
+        st += ["-B"]
+    if rng.random() < 0.3:
+        st += ["-V"]
+    runs.append(("stat", st))
+    fl = list(common)
+    if rng.random() < 0.4:
+        fl += ["-g", pick("0.3", "0.5", "0.9", "1")]
+    used = np.bincount(t.rep_name, minlength=len(t.names))
+    kind = pick("-n", "-c", "-f")
+    if kind == "-n":
+        fl += ["-n", t.names[int(np.argmax(used))] if rng.random() < 0.7 else t.names[int(rng.integers(0, len(t.names)))]]
+    elif kind == "-c":
+        fl += ["-c", t.clas[int(t.cla_of_row[int(rng.integers(0, len(t.start)))])]]
+    else:
+        fl += ["-f", t.fams[int(t.fam_of_row[int(rng.integers(0, len(t.start)))])]]
+    if rng.random() < 0.5:
+        fl += ["-t", str(pick(1, 2, 5))]
+    if rng.random() < 0.5:
+        fl += ["-r"]
+    runs.append(("filter", fl))
+    return runs
+
+
+@pytest.mark.parametrize("seed", list(range(7100, 7148)))
+def test_random_case_matches_reference_binary(seed, exe, tmp_path):
+    rng, chroms, t, r = _random_case(seed)
+    inp = tmp_path / "in"
+    inp.mkdir()
+    synth.write_sizes(str(inp / "chrom.sizes"), chroms)
+    synth.write_sizes(str(inp / "rep.sizes"), t.rep_len.items())
+    synth.write_rmsk(str(inp / "rmsk.txt"), t)
+    as_sam = bool(rng.random() < 0.3)
+    aln = str(inp / ("reads.sam" if as_sam else "reads.bam"))
+    if as_sam:
+        synth.write_sam(aln, r, with_seq=True)
+    else:
+        synth.write_bam(aln, r, with_seq=bool(rng.random() < 0.7), block=int(rng.choice([0xff00, 3000])))
+    for cmd, opts in _random_opts(rng, t):
+        if as_sam:
+            opts = opts + ["-S"]
+        outs = {}
+        for who, prog in (("ref", REF), ("new", exe)):
+            work = tmp_path / f"{cmd}_{who}"
+            work.mkdir()
+            pr = subprocess.run([prog, cmd] + opts + ["-o", "out", str(inp / "chrom.sizes"), str(inp / "rep.sizes"), str(inp / "rmsk.txt"), aln],
+                                cwd=work, capture_output=True, text=True, timeout=600)
+            outs[who] = (pr.returncode, work, pr.stderr)
+        (rc_r, w_r, err_r), (rc_n, w_n, err_n) = outs["ref"], outs["new"]
+        tag = f"seed {seed}: {cmd} {' '.join(opts)}"
+        assert rc_r in (0, 255) or rc_r > 0, f"{tag}: the reference itself died ({rc_r}): {err_r[-500:]}"
+        assert rc_n == rc_r, f"{tag}: exit {rc_n} vs reference {rc_r}\n{err_n[-1500:]}"
+        files_r, files_n = sorted(os.listdir(w_r)), sorted(os.listdir(w_n))
+        assert files_n == files_r, tag
+        for fn in files_r:
+            a, b = (w_r / fn).read_bytes(), (w_n / fn).read_bytes()
+            if fn.endswith(".bigWig"):
+                assert refio.bigwig_digest(b) == refio.bigwig_digest(a), f"{tag}: {fn} decodes differently"
+            else:
+                assert a == b, f"{tag}: {fn} differs"

@@ -59,9 +59,17 @@ def main():
     from __graft_entry__ import build
     if rank == 0:
         build()
+    # rehearsal hook for a one-GPU box (never set by the driver): every rank on cuda:0, gloo instead of RCCL — the same
+    # code path through sharding, export, exchange and the max-over-ranks clock, minus xGMI
+    share_gpu = os.environ.get("ITX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()
     from iteres_amd import dist as idist, engine as eng, synth
     torch.cuda.set_device(local_rank)
@@ -96,6 +104,9 @@ def main():
     # ---------------------------------------------------------------- warmup, then K timed steps + the one exchange
     for _ in range(a.warmup):
         e.submit_device(ptrs, a.reads, stream=stream)
+    # the exchange once, untimed: the first collective of this shape pays for RCCL's channel / buffer set-up
+    e.export_partial(p64.data_ptr(), p32.data_ptr(), stream=stream)
+    idist.reduce_sum_([p64, p32], dist, dst=0)
     e.sync()
     e.reset()
     fence()

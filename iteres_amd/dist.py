@@ -38,6 +38,10 @@ def reduce_sum_(tensors, dist=None, dst=0):
         import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tensors
+    on_gloo_device = dist.get_backend() == "gloo" and any(getattr(t, "is_cuda", False) for t in tensors)
     for t in tensors:
-        dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+        if on_gloo_device:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)        # gloo has no device-tensor reduce; all_reduce gives rank dst the same sum
+        else:
+            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
     return tensors

@@ -8,6 +8,7 @@
 
 #include <ctype.h>
 #include <dlfcn.h>
+#include <omp.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -40,12 +41,21 @@ struct aln_reader {
     /* BGZF state: the file is consumed in chunks of many blocks; the blocks of a chunk are inflated in parallel
      * (they are independent gzip members), then records are located by one sequential hop over the block_len
      * fields and parsed in parallel straight into the staging SoA */
-    uint8_t *cbuf;            /* compressed bytes of the current chunk (+ the incomplete block carried over)   */
-    size_t clen, ccap;
+    uint8_t *cbuf;            /* compressed bytes of the current chunk (+ the incomplete block carried over):   */
+    size_t clen;              /* a window into one of the two raw buffers below                                 */
+    /* raw read-ahead (raw_next): a reader thread freads the next compressed chunk while this one is being inflated */
+    uint8_t *craw[2];
+    size_t io_got;
+    int io_on, io_state, io_stop, io_buf, io_done;   /* io_state: 0 idle, 1 requested, 2 ready; io_done: the file is read out */
+    pthread_t io_thread;
+    pthread_mutex_t io_mu;
+    pthread_cond_t io_cv;
     uint8_t *ubuf;            /* inflated bytes: unconsumed tail of the previous chunk + this chunk            */
     size_t ulen, upos, ucap;
     size_t *rec_off;          /* start of every complete record in ubuf                                        */
     size_t n_rec, rec_next, rec_cap;
+    size_t *spec;             /* locate_records: the pieces' starts before they are accepted                    */
+    size_t spec_cap, hop_pieces, hop_redone;
     int eof;                  /* no more compressed input (end of file or a damaged block)                     */
     struct blk *blk;          /* block index of the chunk being inflated                                        */
     size_t blk_cap;
@@ -128,16 +138,68 @@ static int inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t 
 /* Reads the next chunk of compressed blocks and inflates them in parallel into *pbuf at offset `at` (the buffer is
  * grown as needed, bytes before `at` are kept). Returns the number of bytes inflated; *peof is set when there is no
  * more input (end of file or a damaged block). Touches only the compressed-side state of the reader. */
+/* ---- raw read-ahead: the file is read by its own thread, one chunk ahead, into the spare raw buffer behind RAW_HEAD
+ * bytes of room for the incomplete block the indexer leaves over (less than one BGZF block). */
+#define RAW_HEAD (BGZF_MAX + 64)
+#define RAW_STEP (CHUNK_COMPRESSED < 256 ? (size_t)256 : CHUNK_COMPRESSED)      /* bytes per fread */
+static void *io_main(void *arg)
+{
+    aln_reader *r = arg;
+    pthread_mutex_lock(&r->io_mu);
+    for (;;) {
+        while (r->io_state != 1 && !r->io_stop) pthread_cond_wait(&r->io_cv, &r->io_mu);
+        if (r->io_stop) break;
+        uint8_t *dst = r->craw[r->io_buf] + RAW_HEAD;
+        pthread_mutex_unlock(&r->io_mu);
+        const size_t got = fread(dst, 1, RAW_STEP, r->f);
+        pthread_mutex_lock(&r->io_mu);
+        r->io_got = got;
+        r->io_state = 2;
+        pthread_cond_broadcast(&r->io_cv);
+    }
+    pthread_mutex_unlock(&r->io_mu);
+    return NULL;
+}
+
+/* Appends the next raw chunk behind the carried-over bytes; returns the bytes added (0 once the file is read out). */
+static size_t raw_next(aln_reader *r)
+{
+    if (r->io_done) return 0;
+    if (!r->io_on) {
+        for (int k = 0; k < 2; k++) r->craw[k] = xmalloc(RAW_HEAD + RAW_STEP + 64);
+        pthread_mutex_init(&r->io_mu, NULL);
+        pthread_cond_init(&r->io_cv, NULL);
+        r->io_buf = 0;
+        r->io_state = 1;
+        r->io_stop = 0;
+        if (pthread_create(&r->io_thread, NULL, io_main, r) != 0) die("cannot start the file read-ahead thread");
+        r->io_on = 1;
+    }
+    pthread_mutex_lock(&r->io_mu);
+    while (r->io_state != 2) pthread_cond_wait(&r->io_cv, &r->io_mu);
+    const size_t got = r->io_got;
+    uint8_t *nb = r->craw[r->io_buf];
+    if (r->clen > RAW_HEAD) die("BGZF: %zu bytes left over by the block indexer", r->clen);    /* cannot happen: < one block */
+    if (r->clen) memcpy(nb + RAW_HEAD - r->clen, r->cbuf, r->clen);
+    r->cbuf = nb + RAW_HEAD - r->clen;
+    r->clen += got;
+    r->io_buf ^= 1;
+    if (got == RAW_STEP) {
+        r->io_state = 1;                                          /* the other buffer is free: read on */
+        pthread_cond_broadcast(&r->io_cv);
+    } else {
+        r->io_state = 0;
+        r->io_done = 1;                                           /* a short read: end of file (or an error, same thing here) */
+    }
+    pthread_mutex_unlock(&r->io_mu);
+    return got;
+}
+
 static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, size_t at, int *peof)
 {
-    if (r->ccap < CHUNK_COMPRESSED + BGZF_MAX + 64) {
-        r->ccap = CHUNK_COMPRESSED + BGZF_MAX + 64;
-        r->cbuf = xrealloc(r->cbuf, r->ccap);
-    }
     double tq = now_s();
-    const size_t got = fread(r->cbuf + r->clen, 1, r->ccap - r->clen, r->f);
+    const size_t got = raw_next(r);
     t_io += now_s() - tq;
-    r->clen += got;
     if (r->clen == 0) {
         *peof = 1;
         return 0;
@@ -198,8 +260,8 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
         utot = ok;
         damaged = 1;
     }
-    /* carry the incomplete tail block over */
-    memmove(r->cbuf, r->cbuf + off, r->clen - off);
+    /* the incomplete tail block stays where it is; raw_next carries it over */
+    r->cbuf += off;
     r->clen -= off;
     if (damaged || (got == 0 && nb == 0)) *peof = 1;
     return utot;
@@ -417,8 +479,8 @@ void aln_close(aln_reader *r)
 {
     if (!r) return;
     if (getenv("ITX_TIMING") && !r->is_sam)
-        fprintf(stderr, "[itx timing] BAM decode so far: file read %.3f s, inflate (%s) %.3f s, record hop %.3f s, parse %.3f s\n", t_io,
-                ld_state == 1 ? "libdeflate" : "zlib", t_inflate, t_hop, t_parse);
+        fprintf(stderr, "[itx timing] BAM decode so far: file read %.3f s, inflate (%s) %.3f s, record hop %.3f s (%zu pieces, %zu walked again), parse %.3f s\n", t_io,
+                ld_state == 1 ? "libdeflate" : "zlib", t_inflate, t_hop, r->hop_pieces, r->hop_redone, t_parse);
     if (r->pf_on) {
         pthread_mutex_lock(&r->pf_mu);
         while (r->pf_state == 1) pthread_cond_wait(&r->pf_cv, &r->pf_mu);      /* let a chunk in flight land */
@@ -427,15 +489,25 @@ void aln_close(aln_reader *r)
         pthread_mutex_unlock(&r->pf_mu);
         pthread_join(r->pf_thread, NULL);
     }
+    if (r->io_on) {
+        pthread_mutex_lock(&r->io_mu);
+        while (r->io_state == 1) pthread_cond_wait(&r->io_cv, &r->io_mu);      /* let a read in flight land */
+        r->io_stop = 1;
+        pthread_cond_broadcast(&r->io_cv);
+        pthread_mutex_unlock(&r->io_mu);
+        pthread_join(r->io_thread, NULL);
+    }
     if (r->f) fclose(r->f);
+    free(r->craw[0]);
+    free(r->craw[1]);
     free(r->nbuf);
     free(r->blk);
     for (int i = 0; i < r->n_targets; i++) free(r->tname[i]);
     free(r->tname);
     names_free(&r->tnames);
-    free(r->cbuf);
     free(r->ubuf);
     free(r->rec_off);
+    free(r->spec);
     free(r->line);
     free(r);
 }
@@ -532,6 +604,175 @@ static inline void bam_parse_one(const uint8_t *p, size_t n, itx_staging *st, al
     }
 }
 
+/* ---- locating the records --------------------------------------------------------------------------------------
+ * A BAM stream is a chain: a record's length field says where the next record starts (bam.c:179-210 reads them one by one).
+ * Walking that chain is a pointer chase through hundreds of megabytes per chunk — one core, one cache miss per record. The
+ * chunk is cut into pieces instead and every piece is walked by its own thread from a GUESSED start: the first offset in the
+ * piece from which a few records in a row look like records. A guess proves nothing by itself; what makes the result exact
+ * is the check afterwards, in stream order: piece 0 starts at a known record start, and a piece is accepted only if its
+ * guess is precisely where the chain of the pieces before it arrives — otherwise that piece is walked again from there. */
+typedef struct {
+    size_t c, end, n, first;   /* guessed start (SIZE_MAX none), where the walk stopped, starts found, their place in spec */
+    int why;                   /* 0 reached the piece's limit, 1 needs more input, 2 malformed length (bam.c:186-190) */
+} hop_piece;
+
+static size_t hop_run(const uint8_t *u, size_t p, size_t lim, size_t L, size_t *off, size_t *pn, int *why)
+{
+    size_t n = *pn;
+    while (p < lim) {
+        if (p + 4 > L) {
+            *why = 1;
+            *pn = n;
+            return p;
+        }
+        __builtin_prefetch(u + p + 1024);
+        __builtin_prefetch(u + p + 2048);
+        const int32_t bl = rd_i32(u + p);
+        if (bl < 32) {
+            *why = 2;
+            *pn = n;
+            return p;
+        }
+        if (p + 4 + (size_t)bl > L) {
+            *why = 1;
+            *pn = n;
+            return p;
+        }
+        off[n++] = p;
+        p += 4 + (size_t)bl;
+    }
+    *why = 0;
+    *pn = n;
+    return p;
+}
+
+/* does a complete record that looks like one start at p? (only ever used to pick a guess) */
+static inline size_t looks_like_record(const uint8_t *u, size_t p, size_t L, int n_targets)
+{
+    if (p + 36 > L) return 0;
+    const int32_t bl = rd_i32(u + p);
+    if (bl < 32 || p + 4 + (size_t)bl > L) return 0;
+    const uint8_t *core = u + p + 4;
+    const int32_t tid = rd_i32(core), pos = rd_i32(core + 4), l_qseq = rd_i32(core + 16), mtid = rd_i32(core + 20), mpos = rd_i32(core + 24);
+    const uint32_t x1 = rd_u32(core + 8), x2 = rd_u32(core + 12);
+    const size_t l_qname = x1 & 0xff, n_cigar = x2 & 0xffff;
+    if (tid < -1 || tid >= n_targets || mtid < -1 || mtid >= n_targets || pos < -1 || mpos < -1 || l_qseq < 0 || l_qname == 0) return 0;
+    const size_t need = l_qname + 4 * n_cigar + ((size_t)l_qseq + 1) / 2 + (size_t)l_qseq;
+    if (need > (size_t)bl - 32) return 0;
+    if (u[p + 36 + l_qname - 1] != 0) return 0;
+    return 4 + (size_t)bl;
+}
+
+static size_t hop_piece_bytes(void)
+{
+    static size_t v;
+    if (!v) {
+        const char *e = getenv("ITX_HOP_PIECE");                  /* tests force tiny pieces: many guesses, many of them wrong */
+        const long x = e ? atol(e) : 0;
+        v = x >= 1 ? (size_t)x : (1u << 20);
+    }
+    return v;
+}
+
+/* Fills rec_off / n_rec with the starts of the complete records in ubuf[upos, ulen), exactly as the one-by-one walk would;
+ * sets upos behind the last of them (when there is one), and eof / ulen at a malformed length. */
+static void locate_records(aln_reader *r)
+{
+    const uint8_t *u = r->ubuf;
+    const size_t p0 = r->upos, L = r->ulen;
+    r->n_rec = r->rec_next = 0;
+    if (p0 >= L) return;
+    const size_t worst = (L - p0) / 36 + 2;                        /* a record is at least 36 bytes */
+    const size_t piece = hop_piece_bytes();
+    size_t T = (L - p0) / piece;
+    const size_t tmax = (size_t)omp_get_max_threads() * 8;
+    if (T > tmax) T = tmax;
+    if (r->rec_cap < worst) {
+        r->rec_cap = worst + worst / 4;
+        r->rec_off = xrealloc(r->rec_off, sizeof(size_t) * r->rec_cap);
+    }
+    size_t p;
+    int why = 0;
+    if (T < 2) {
+        p = hop_run(u, p0, L, L, r->rec_off, &r->n_rec, &why);
+    } else {
+        if (r->spec_cap < worst + T) {
+            r->spec_cap = worst + worst / 4 + T;
+            r->spec = xrealloc(r->spec, sizeof(size_t) * r->spec_cap);
+        }
+        hop_piece *pc = xcalloc(T, sizeof *pc);
+        const size_t span = (L - p0) / T;
+        const int n_targets = r->n_targets;
+        size_t *spec = r->spec;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long t = 0; t < (long)T; t++) {
+            const size_t b = p0 + (size_t)t * span, lim = (size_t)t + 1 < T ? p0 + ((size_t)t + 1) * span : L;
+            hop_piece *q = &pc[t];
+            q->first = (b - p0) / 36 + (size_t)t;                  /* room for every start this piece can hold */
+            q->c = SIZE_MAX;
+            q->n = 0;
+            if (t == 0) {
+                q->c = b;
+            } else {
+                for (size_t c = b; c < lim; c++) {
+                    size_t a = c, k = 0;
+                    while (k < 3 && a < L) {                       /* three in a row, or up to the end of what is inflated */
+                        const size_t step = looks_like_record(u, a, L, n_targets);
+                        if (!step) break;
+                        a += step;
+                        k++;
+                    }
+                    if (k == 3 || (k > 0 && a >= L)) {
+                        q->c = c;
+                        break;
+                    }
+                }
+            }
+            q->end = q->c;
+            if (q->c != SIZE_MAX) q->end = hop_run(u, q->c, lim, L, spec + q->first, &q->n, &q->why);
+        }
+        /* in stream order: accept a piece whose guess is where the chain arrives, walk it again otherwise */
+        size_t cur = p0;
+        p = p0;
+        for (size_t t = 0; t < T; t++) {
+            const size_t lim = t + 1 < T ? p0 + (t + 1) * span : L;
+            hop_piece *q = &pc[t];
+            if (cur >= lim) {                                      /* a record reaches over the whole piece */
+                q->n = 0;
+                continue;
+            }
+            if (q->c != cur) {
+                q->n = 0;
+                q->end = hop_run(u, cur, lim, L, spec + q->first, &q->n, &q->why);
+                r->hop_redone++;
+            }
+            p = cur = q->end;
+            why = q->why;
+            if (why) {
+                for (size_t k = t + 1; k < T; k++) pc[k].n = 0;
+                break;
+            }
+        }
+        size_t tot = 0;
+        for (size_t t = 0; t < T; t++) {
+            const size_t n = pc[t].n;
+            pc[t].c = tot;                                         /* reused: the piece's place in rec_off */
+            tot += n;
+        }
+#pragma omp parallel for schedule(static)
+        for (long t = 0; t < (long)T; t++)
+            if (pc[t].n) memcpy(r->rec_off + pc[t].c, spec + pc[t].first, sizeof(size_t) * pc[t].n);
+        r->n_rec = tot;
+        r->hop_pieces += T;
+        free(pc);
+    }
+    if (why == 2) {                                                /* bam.c:186-190: a malformed length ends the file */
+        r->eof = 1;
+        r->ulen = p;
+    }
+    if (r->n_rec) r->upos = p;                                     /* consumed up to here once these are parsed */
+}
+
 static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
     size_t n = 0;
@@ -542,29 +783,8 @@ static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_sid
             r->n_rec = r->rec_next = 0;
             double th = now_s();
             for (;;) {
-                size_t p = r->upos;
-                while (p + 4 <= r->ulen) {
-                    /* the hop is a pointer chase through bytes other cores have just written: ask for the lines ahead */
-                    __builtin_prefetch(r->ubuf + p + 1024);
-                    __builtin_prefetch(r->ubuf + p + 2048);
-                    const int32_t bl = rd_i32(r->ubuf + p);
-                    if (bl < 32) {                                /* bam.c:186-190: a malformed length ends the file */
-                        r->eof = 1;
-                        r->ulen = p;
-                        break;
-                    }
-                    if (p + 4 + (size_t)bl > r->ulen) break;
-                    if (r->n_rec == r->rec_cap) {
-                        r->rec_cap = r->rec_cap ? r->rec_cap * 2 : 1 << 20;
-                        r->rec_off = xrealloc(r->rec_off, sizeof(size_t) * r->rec_cap);
-                    }
-                    r->rec_off[r->n_rec++] = p;
-                    p += 4 + (size_t)bl;
-                }
-                if (r->n_rec) {
-                    r->upos = p;                                  /* consumed up to here once these are parsed */
-                    break;
-                }
+                locate_records(r);
+                if (r->n_rec) break;
                 const double tl = now_s();
                 const size_t more = bgzf_load_chunk(r);
                 th += now_s() - tl;                               /* the load is accounted as io / inflate */

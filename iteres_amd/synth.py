@@ -304,6 +304,9 @@ def _aux_bin(fields):
             out += b"Z" + val.encode() + b"\0"
         elif ty == "A":
             out += b"A" + val.encode()[:1]
+        elif ty == "B":                                  # "XY:B:<hex>": a uint8 array holding exactly these bytes
+            raw = bytes.fromhex(val)
+            out += b"BC" + struct.pack("<I", len(raw)) + raw
         else:
             raise ValueError(ty)
     return bytes(out)

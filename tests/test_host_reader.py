@@ -23,10 +23,12 @@ def dump(tmp_path_factory):
     return exe
 
 
-def run_dump(exe, path, is_sam, batch=4096, threads=4, chunk=None):
+def run_dump(exe, path, is_sam, batch=4096, threads=4, chunk=None, piece=None):
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     if chunk:
         env["ITX_BGZF_CHUNK"] = str(chunk)          # compressed bytes per read-ahead step: small = many buffer swaps
+    if piece:
+        env["ITX_HOP_PIECE"] = str(piece)           # bytes per piece of the parallel record search: small = many guesses
     pr = subprocess.run([exe, path, str(int(is_sam)), str(batch)], capture_output=True, text=True, env=env)
     assert pr.returncode == 0, pr.stderr
     hdr, recs, tail = [], [], None
@@ -61,7 +63,37 @@ def test_golden_alignment_files(case, dump, tmp_path):
         for batch in (4096, 777):
             hdr, recs, tail, _ = run_dump(dump, path, name.endswith(".sam"), batch)
             check(hdr, recs, header, rd)
+        hdr, recs, tail, _ = run_dump(dump, path, name.endswith(".sam"), 4096, threads=3, piece=200)
+        check(hdr, recs, header, rd)
         assert f"paired={int(bool((rd['flag'] & 1).any()))}" in tail
+
+
+def test_record_search_recovers_from_wrong_guesses(dump, tmp_path):
+    """Every record carries, in a byte-array tag, three well-formed little records in a row and then a length that leads
+    off into the weeds: a piece that begins inside such a record guesses the decoy as its start. The stream-order check
+    (bamio.c locate_records) must notice and walk those pieces again — the records that come out are the file's own."""
+    import struct
+    chroms = [("c1", 3_000_000)]
+    r = synth.make_reads(78, chroms, 12_000, read_len=(30, 60), paired_frac=0.2)
+    fake = struct.pack("<iiiIIiiii", 40, 0, 5, 2 | (30 << 8), 0, 0, -1, -1, 0) + b"a\0" + bytes(6)
+    decoy = (fake * 3 + struct.pack("<i", 33) + bytes(range(40, 80))).hex()
+    r.aux = [[f"ZZ:B:{decoy}"] if i % 3 else [] for i in range(len(r))]
+    path = str(tmp_path / "decoy.bam")
+    synth.write_bam(path, r, with_seq=True)
+    header, rd = refio.read_bam(path)
+    redone = 0
+    for piece, threads in ((300, 4), (700, 3), (5000, 5)):
+        env_t = dict(ITX_TIMING="1")
+        os.environ.update(env_t)
+        try:
+            hdr, recs, tail, err = run_dump(dump, path, False, batch=5000, threads=threads, piece=piece)
+        finally:
+            os.environ.pop("ITX_TIMING")
+        check(hdr, recs, header, rd)
+        line = [l for l in err.split("\n") if "walked again" in l]
+        assert line, err
+        redone += int(line[0].split("pieces, ")[1].split(" walked")[0])
+    assert redone > 0                       # the decoys did mislead some pieces, and the result is exact all the same
 
 
 def test_many_small_blocks_and_truncation(dump, tmp_path):
@@ -79,6 +111,11 @@ def test_many_small_blocks_and_truncation(dump, tmp_path):
     for chunk, batch in ((3000, 9999), (50_000, 1234), (1, 4096)):
         hdr, recs, tail, _ = run_dump(dump, path, False, batch=batch, threads=3, chunk=chunk)
         check(hdr, recs, header, rd)
+    # the record search in pieces (bamio.c locate_records): pieces smaller than a record, of a few records, of many; with
+    # and without sequence bytes (whose random content is where false guesses come from)
+    for piece, threads, chunk in ((40, 4, None), (150, 3, None), (1000, 5, 50_000), (20_000, 2, None), (1 << 20, 4, None)):
+        hdr, recs, tail, _ = run_dump(dump, path, False, batch=9999, threads=threads, chunk=chunk, piece=piece)
+        check(hdr, recs, header, rd)
     # truncated in the middle of a block: a clean prefix of the records, no crash
     data = open(path, "rb").read()
     cut = str(tmp_path / "cut.bam")
@@ -86,6 +123,8 @@ def test_many_small_blocks_and_truncation(dump, tmp_path):
     hdr, recs, tail, _ = run_dump(dump, cut, False, batch=4096)
     assert 0 < len(recs) < len(rd["tid"])
     hdr2, recs2, _, _ = run_dump(dump, cut, False, batch=4096, chunk=20_000)
+    assert recs2 == recs
+    hdr2, recs2, _, _ = run_dump(dump, cut, False, batch=4096, piece=500)
     assert recs2 == recs
     for i in (0, len(recs) // 2, len(recs) - 1):
         assert int(recs[i][1]) == int(rd["pos"][i]) and recs[i][7] == rd["qname"][i]

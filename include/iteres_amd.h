@@ -209,6 +209,27 @@ typedef struct itx_stats {
 } itx_stats;
 int itx_engine_get_stats(itx_engine *e, itx_stats *out);
 
+/* ---- BGZF inflate on the device --------------------------------------------------------------------------------
+ * Replaces the reference's per-block zlib inflate (cussamtools/bgzf.c:367-397 inflate_block, reached from
+ * bgzf_read -> bgzf_read_block, bgzf.c:425-521). The caller indexes the blocks of a chunk of the file (header
+ * check bgzf.c:401-411, BSIZE, ISIZE trailer) and hands over the compressed chunk; every block is decoded by one
+ * wavefront into its place in `out`. Offsets are relative to `comp` / `out`; uoff must be the running sum of the
+ * usize's (the inflated bytes are contiguous). `comp` needs 8 readable bytes past comp_len. status[i] = 0 when block
+ * i inflated to exactly usize bytes, else a small positive code (the data is damaged or the decoder declined it —
+ * the caller's zlib has the last word, as in the reference). Synchronous; one calling thread per inflater. */
+typedef struct itx_inflater itx_inflater;
+typedef struct itx_bgzf_block {
+    uint32_t coff, csize;         /* the whole gzip member: 18-byte header, deflate data, CRC32, ISIZE */
+    uint32_t uoff, usize;
+} itx_bgzf_block;
+int itx_inflater_create(int device, itx_inflater **out);
+void itx_inflater_destroy(itx_inflater *h);
+int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, void *out, size_t out_len,
+                     uint8_t *status);
+/* Page-locked host memory for the buffers that cross PCIe on every call (NULL when it cannot be had). */
+void *itx_pinned_alloc(size_t bytes);
+void itx_pinned_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

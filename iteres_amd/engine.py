@@ -23,6 +23,7 @@ EXPORTS = [
     "itx_engine_staging", "itx_engine_submit_slot", "itx_engine_classify_slot", "itx_engine_wait_slot", "itx_engine_submit_device",
     "itx_engine_classify_device", "itx_engine_first_hit_slot", "itx_engine_first_hit_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
     "itx_engine_partial_size", "itx_engine_export_partial", "itx_engine_finish_partial",
+    "itx_inflater_create", "itx_inflater_destroy", "itx_inflate_bgzf", "itx_pinned_alloc", "itx_pinned_free",
 ]
 
 
@@ -105,6 +106,14 @@ def load():
     L.itx_engine_reset.argtypes = [C.c_void_p]
     L.itx_engine_finish.argtypes = [C.c_void_p, C.POINTER(Result)]
     L.itx_engine_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.itx_inflater_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.itx_inflater_destroy.argtypes = [C.c_void_p]
+    L.itx_inflater_destroy.restype = None
+    L.itx_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.itx_pinned_alloc.argtypes = [C.c_size_t]
+    L.itx_pinned_alloc.restype = C.c_void_p
+    L.itx_pinned_free.argtypes = [C.c_void_p]
+    L.itx_pinned_free.restype = None
     _lib = L
     return L
 
@@ -304,6 +313,56 @@ class Engine:
         if getattr(self, "_h", None):
             load().itx_engine_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+BGZF_BLOCK = np.dtype([("coff", np.uint32), ("csize", np.uint32), ("uoff", np.uint32), ("usize", np.uint32)])
+
+
+def index_bgzf(buf) -> np.ndarray:
+    """The complete BGZF blocks of a byte buffer (what the host reader's indexer finds: header check, BSIZE, ISIZE)."""
+    b = np.frombuffer(buf, np.uint8)
+    out, off, uoff = [], 0, 0
+    while off + 18 <= len(b):
+        h = b[off:off + 18]
+        if not (h[0] == 31 and h[1] == 139 and h[2] == 8 and (h[3] & 4) and h[12] == 66 and h[13] == 67):
+            break
+        bsize = int(h[16]) + (int(h[17]) << 8) + 1
+        if off + bsize > len(b):
+            break
+        usize = int.from_bytes(bytes(b[off + bsize - 4:off + bsize]), "little")
+        out.append((off, bsize, uoff, usize))
+        off += bsize
+        uoff += usize
+    return np.array(out, BGZF_BLOCK)
+
+
+class Inflater:
+    """itx_inflate_bgzf: the BGZF blocks of a compressed chunk, one wavefront each (include/iteres_amd.h)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _chk(load().itx_inflater_create(device, C.byref(self._h)), "itx_inflater_create")
+
+    def inflate(self, comp: bytes, blocks: np.ndarray | None = None):
+        blocks = index_bgzf(comp) if blocks is None else np.ascontiguousarray(blocks, BGZF_BLOCK)
+        cbuf = np.zeros(len(comp) + 16, np.uint8)
+        cbuf[:len(comp)] = np.frombuffer(comp, np.uint8)
+        total = int(blocks["usize"].astype(np.uint64).sum())
+        out = np.zeros(total + 16, np.uint8)
+        status = np.full(max(len(blocks), 1), 255, np.uint8)
+        _chk(load().itx_inflate_bgzf(self._h, _p(cbuf), len(comp), _p(blocks), len(blocks), _p(out), total, _p(status)), "itx_inflate_bgzf")
+        return out[:total], status[:len(blocks)]
+
+    def close(self):
+        if self._h:
+            load().itx_inflater_destroy(self._h)
+            self._h = C.c_void_p()
 
     def __del__(self):
         try:

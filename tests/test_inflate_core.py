@@ -1,0 +1,121 @@
+"""The wave's DEFLATE decoder (iteres_amd/csrc/itx_inflate_core.h — the kernel that replaces the reference's per-block zlib
+inflate, cussamtools/bgzf.c:367-397) built for the host with a one-lane wave (tests/inflate_host.cpp) and checked against
+zlib: every block type, every compression level and strategy, matches at every distance up to 32 KiB, self-overlapping
+matches, blocks at odd offsets in the compressed buffer and in the output, and damaged input (must fail cleanly or —
+when it decodes — agree with what zlib makes of the same bytes)."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("inflate") / "libinflate_host.so")
+    subprocess.check_call(["g++", "-O2", "-g", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", so, os.path.join(ROOT, "tests", "inflate_host.cpp")])
+    L = C.CDLL(so)
+    L.itx_inflate_host.restype = C.c_int
+    L.itx_inflate_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    return L
+
+
+def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, memlevel=8):
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return co.compress(data) + co.flush()
+
+
+def run(lib, comp, usize, at=0, g0=0, pad_out=0):
+    """comp placed `at` bytes into a word buffer; output written at offset g0 of a buffer with guard bytes around"""
+    buf = np.zeros((at + len(comp) + 16 + 3) // 4 + 2, np.uint32)
+    buf.view(np.uint8)[at:at + len(comp)] = np.frombuffer(comp, np.uint8)
+    out = np.full(g0 + usize + 64 + pad_out, 0xA5, np.uint8)
+    rc = lib.itx_inflate_host(buf.ctypes.data, at, at + len(comp), out.ctypes.data, g0, usize)
+    assert (out[:g0] == 0xA5).all() and (out[g0 + usize:] == 0xA5).all(), "wrote outside its block"
+    return rc, out[g0:g0 + usize].tobytes()
+
+
+def corpus(rng):
+    yield b""
+    yield b"a"
+    yield b"abc" * 5
+    yield bytes(70000 % 65280)
+    yield bytes(rng.integers(0, 256, 65280, dtype=np.uint8))                      # incompressible: stored blocks at level >= 1
+    yield bytes(rng.integers(0, 4, 65280, dtype=np.uint8))                        # tiny alphabet: short codes, long matches
+    yield (b"ACGT" * 7 + b"N") * 2200
+    yield bytes(rng.integers(65, 91, 40000, dtype=np.uint8)) + bytes(25000)
+    # BAM-like records: little-endian ints, names, 4-bit sequence, quality runs
+    rec = bytearray()
+    for i in range(400):
+        rec += int(rng.integers(0, 1 << 28)).to_bytes(4, "little") * 3 + f"read{i}".encode() + b"\0" + bytes(rng.integers(0, 256, 50, dtype=np.uint8)) + bytes([40]) * 100
+    yield bytes(rec)
+    # far matches: a random kilobyte repeated at distances up to the 32 KiB window
+    base = bytes(rng.integers(0, 256, 1000, dtype=np.uint8))
+    for gap in (7000, 7800, 7900, 8200, 20000, 31700):
+        yield base + bytes(rng.integers(0, 256, gap - 1000, dtype=np.uint8)) + base + bytes(rng.integers(0, 256, 500, dtype=np.uint8)) + base[:300]
+    # self-overlapping matches of every small distance
+    for d in (1, 2, 3, 5, 7, 31, 32, 33, 63, 64, 65, 100, 257, 258, 259):
+        yield bytes(rng.integers(0, 256, d, dtype=np.uint8)) * (3000 // d + 2)
+
+
+def test_against_zlib_every_level_and_strategy(lib):
+    rng = np.random.default_rng(5)
+    n = 0
+    for data in corpus(rng):
+        for level in (0, 1, 4, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                comp = raw_deflate(data, level, strategy)
+                for at, g0 in ((0, 0), (18, 0), (1, 3), (2, 255), (3, 256), (7, 70001)):
+                    rc, out = run(lib, comp, len(data), at, g0)
+                    assert rc == 0, (len(data), level, strategy, at, g0, rc)
+                    assert out == data
+                    n += 1
+    assert n > 3000
+
+
+def test_small_windows_and_memlevels_many_blocks(lib):
+    rng = np.random.default_rng(6)
+    text = bytes(rng.choice(np.frombuffer(b"ACGTNacgtn\t\n0123456789", np.uint8), 65000))
+    for wbits in (-9, -12, -15):
+        for memlevel in (1, 3, 9):                  # memlevel 1: a new dynamic block every few hundred symbols
+            comp = raw_deflate(text, 6, zlib.Z_DEFAULT_STRATEGY, wbits, memlevel)
+            rc, out = run(lib, comp, len(text), 5, 77)
+            assert rc == 0 and out == text
+
+
+def test_wrong_size_and_truncation_fail_cleanly(lib):
+    rng = np.random.default_rng(7)
+    data = bytes(rng.integers(0, 7, 30000, dtype=np.uint8))
+    comp = raw_deflate(data, 6)
+    assert run(lib, comp, len(data) - 1)[0] != 0          # the trailer promised fewer bytes
+    assert run(lib, comp, len(data) + 1)[0] != 0          # ... or more
+    for cut in (1, 2, 10, len(comp) // 2, len(comp) - 1):
+        rc, _ = run(lib, comp[:cut], len(data))
+        assert rc != 0
+
+
+def test_damaged_streams_never_disagree_with_zlib(lib):
+    rng = np.random.default_rng(8)
+    agree = fail = 0
+    for trial in range(1500):
+        data = bytes(rng.integers(0, int(rng.choice([2, 5, 64, 256])), int(rng.integers(1, 5000)), dtype=np.uint8))
+        comp = bytearray(raw_deflate(data, int(rng.choice([1, 6, 9])), int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED]))))
+        for _ in range(int(rng.integers(1, 4))):
+            comp[int(rng.integers(0, len(comp)))] ^= 1 << int(rng.integers(0, 8))
+        rc, out = run(lib, bytes(comp), len(data), int(rng.integers(0, 4)), int(rng.integers(0, 600)))
+        if rc != 0:
+            fail += 1
+            continue
+        # it decoded to exactly len(data) bytes: zlib must produce the same bytes from the same input
+        d = zlib.decompressobj(-15)
+        try:
+            ref = d.decompress(bytes(comp))
+        except zlib.error:
+            ref = None
+        assert ref is not None and ref[:len(data)] == out, trial
+        agree += 1
+    assert fail > 100 and agree > 10

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Scratch measurement: itx_inflate_bgzf on a synthetic BAM (tools/mkbam.c), whole call and kernel-only, next to zlib
+on one host core.   python tools/inflate_measure.py [n_reads=2000000] [seq_len=100] [repeat=3]"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from iteres_amd import engine as eng, synth  # noqa: E402
+
+
+def main():
+    n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    seq_len = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    mk = os.path.join(ROOT, "tools", "mkbam")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", mk, os.path.join(ROOT, "tools", "mkbam.c"), "-lz"])
+    tmp = tempfile.mkdtemp(prefix="itx_inf_")
+    synth.write_sizes(os.path.join(tmp, "chrom.sizes"), synth.HG38_CHROMS)
+    subprocess.check_call([mk, os.path.join(tmp, "chrom.sizes"), str(n_reads), os.path.join(tmp, "reads.bam"), str(seq_len), "7"])
+    comp = open(os.path.join(tmp, "reads.bam"), "rb").read()
+    blocks = eng.index_bgzf(comp)
+    total = int(blocks["usize"].astype(np.uint64).sum())
+    print(f"{len(comp) / 1e6:.1f} MB compressed, {total / 1e6:.1f} MB inflated, {len(blocks)} blocks", flush=True)
+    L = eng.load()
+    h = eng.Inflater()
+    import ctypes as C
+    cp = L.itx_pinned_alloc(len(comp) + 64)
+    op = L.itx_pinned_alloc(total + 64)
+    C.memmove(cp, comp, len(comp))
+    status = np.zeros(len(blocks), np.uint8)
+    for it in range(repeat):
+        t0 = time.perf_counter()
+        eng._chk(L.itx_inflate_bgzf(h._h, cp, len(comp), eng._p(blocks), len(blocks), op, total, eng._p(status)), "inflate")
+        dt = time.perf_counter() - t0
+        print(f"call {it}: {dt * 1e3:.1f} ms -> {total / dt / 1e9:.2f} GB/s inflated, bad blocks {int((status != 0).sum())}", flush=True)
+    out = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(total,))
+    t0 = time.perf_counter()
+    nchk = min(len(blocks), 400)
+    ok = True
+    for b in blocks[:nchk]:
+        ref = zlib.decompress(comp[int(b["coff"]) + 18:int(b["coff"]) + int(b["csize"]) - 8], -15)
+        ok = ok and out[int(b["uoff"]):int(b["uoff"]) + int(b["usize"])].tobytes() == ref
+    dz = time.perf_counter() - t0
+    usz = int(blocks["usize"][:nchk].astype(np.uint64).sum())
+    print(f"first {nchk} blocks equal zlib: {ok}; zlib on one core {usz / dz / 1e9:.2f} GB/s", flush=True)
+    L.itx_pinned_free(cp)
+    L.itx_pinned_free(op)
+    h.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -226,6 +226,8 @@ int itx_inflater_create(int device, itx_inflater **out);
 void itx_inflater_destroy(itx_inflater *h);
 int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, void *out, size_t out_len,
                      uint8_t *status);
+/* Device time of the two passes of the last call (Huffman -> tokens; first group of tokens -> bytes), milliseconds. */
+int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve_ms);
 /* Page-locked host memory for the buffers that cross PCIe on every call (NULL when it cannot be had). */
 void *itx_pinned_alloc(size_t bytes);
 void itx_pinned_free(void *p);

@@ -1,33 +1,47 @@
-// itx_inflate_core.h — raw DEFLATE (RFC 1951) of ONE BGZF block by ONE wavefront.
+// itx_inflate_core.h — raw DEFLATE (RFC 1951) of BGZF blocks on a GPU, in two passes.
 //
 // What it replaces: the per-block zlib `inflate` of the reference's reader (cussamtools/bgzf.c:367-397 inflate_block,
 // called from bgzf_read_block, bgzf.c:425-466) — a BAM is a sequence of independent gzip members of at most 64 KiB, so a
 // chunk of the file is thousands of independent decodes.
 //
-// Shape on CDNA4: one wave per block, thousands of waves in flight. Huffman decoding is a serial bit chase, so the wave
-// runs it as a UNIFORM program — all 64 lanes carry the same bit buffer and take the same branches (values the compiler
-// keeps in scalar registers where it can) — and uses its width where the format is wide: match copies, stored blocks and
-// the write-back move 64 bytes per step. Output is staged in an 8 KiB LDS ring addressed by the GLOBAL output offset, so
-// every 256-byte stripe that fills up leaves as one coalesced 16-byte-per-lane store; matches read the ring (LDS is in
-// order within a wave: no barriers), and the few that reach further back than the ring read what was already written
-// back, behind a fence. Codes are decoded canonically from per-length counts held in registers (no table build beyond a
-// counting sort of the symbols), after Mark Adler's puff.c description of the format.
+// DEFLATE has two halves of very different shape, and each gets the mapping that suits it:
 //
-// The same source compiles for the host with ITXI_WAVE == 1 (tests/inflate_host.cpp): the CPU test suite fuzzes it
+//   pass 1, itxi_tokens — the Huffman half is a serial bit chase per block with no use for a wide machine inside one
+//     block (a wave running it as one uniform program is bound by the CU's one-scalar-instruction-per-cycle issue:
+//     measured 8 GB/s on the chip). So here every LANE decodes its own block: 64 blocks per wave, all state in the lane's
+//     registers (bit buffer, canonical-code counts), the symbol tables lane-interleaved in LDS (bank = lane: no
+//     conflicts whatever the symbols). It needs no output window: it writes the block's LITERALS as a byte string and
+//     its MATCHES as (literals before, length, distance) tokens.
+//   pass 2, itxi_resolve — the LZ77 half is memory movement: one WAVE per block replays the tokens, 64 bytes per step,
+//     in an 8 KiB LDS ring addressed by the global output offset; every 256-byte stripe that fills up leaves as one
+//     coalesced store. Matches read the ring (LDS is in order within a wave: no barriers); the few that reach further
+//     back read what was already written back, behind a fence.
+//
+// Codes are decoded canonically from per-length counts (a counting sort of the symbols is the whole table build), after
+// Mark Adler's puff.c description of the format.
+//
+// The same source compiles for the host (tests/inflate_host.cpp: one-lane "wave", plain arrays): the CPU suite fuzzes it
 // against zlib before any of it runs on a GPU. Every loop is bounded by input consumed or output produced; any
 // inconsistency ends the block with a non-zero status and the caller decides (the host re-inflates such a block with
 // zlib, whose verdict is the reference's).
+//
+// Hooks the including file defines: ITXI_FN (function attributes), ITXI_WAVE (lanes that share pass 2: 64 / 1),
+// ITXI_UNI(x) (pass 2: a wave-uniform value as such), ITXI_AT(p, i) (pass 1: element i of a per-decoder table: lane-
+// interleaved on the device, using the lane id `ln` in scope), ITXI_BCAST(v, j) (pass 2: lane j's v, for all),
+// ITXI_LOADW / ITXI_LOADB (global loads), ITXI_FENCE().
 #pragma once
 #include <stdint.h>
 
 #ifndef ITXI_WAVE
-#error "define ITXI_WAVE (64 on the device, 1 on the host) and the ITXI_* hooks before including this file"
+#error "define the ITXI_* hooks before including this file"
 #endif
 
-#define ITXI_RING 8192u                    // bytes of output kept in LDS; a power of two, a multiple of the stripe
+#define ITXI_RING 8192u                    // pass 2: bytes of output kept in LDS; a power of two, a multiple of the stripe
 #define ITXI_MASK (ITXI_RING - 1u)
 #define ITXI_STRIPE 256u                   // write-back granule: 64 lanes x 4 bytes
 #define ITXI_NEAR (ITXI_RING - 320u)       // matches up to this distance read the ring (a match writes at most 258 bytes ahead)
+#define ITXI_MAX_BLOCK 65536u              // BGZF: a block inflates to at most 64 KiB
+#define ITXI_MAX_TOK (ITXI_MAX_BLOCK / 3u + 1u)       // a match is at least 3 bytes
 
 enum {
     ITXI_OK = 0,
@@ -40,11 +54,12 @@ enum {
     ITXI_E_DIST = 7,        // distance reaches before the start of the block
 };
 
-struct ItxiLds {
-    uint32_t ring32[ITXI_RING / 4];
-    uint16_t lsym[288], dsym[32];          // symbols in canonical order (by code length, then symbol)
-    uint16_t offs[16];
-    uint8_t lens[352];                     // code lengths being set up: literal/length at 0, distance at 288, code-length code at 320
+// ---------------------------------------------------------------------------------------------------- pass 1: tokens
+
+struct ItxiTab {                           // one decoder's tables (element i through ITXI_AT)
+    uint16_t *lsym, *dsym;                 // [288], [32]: symbols in canonical order (by code length, then symbol)
+    uint16_t *offs;                        // [16]
+    uint8_t *lens;                         // [352]: code lengths being set up: literal/length at 0, distance at 288, code-length code at 320
 };
 
 struct ItxiCodes {                         // counts per code length 1..15, two to a word (length 2k+1 low, 2k+2 high)
@@ -94,41 +109,39 @@ ITXI_FN bool itxi_overrun(const ItxiIn &in)                 // a bit of a byte a
 
 // One symbol of a canonical code (puff.c decode()): codes of each length are consecutive integers, shorter codes first.
 // `peek` holds the next 15 stream bits; returns the symbol's index in canonical order and its length, or len = 0.
+// Branch-free over the 15 lengths: the lanes of a wave decode different codes, so every length is visited anyway.
 ITXI_FN uint32_t itxi_decode(const ItxiCodes &h, uint32_t peek, uint32_t &len_out)
 {
     int32_t code = 0, first = 0, index = 0;
+    uint32_t len_found = 0, at = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int len = 2 * k + half + 1;
-            if (len > 15) break;
-            code |= (int32_t)(peek & 1u);
-            peek >>= 1;
-            const int32_t count = (int32_t)(half ? h.c[k] >> 16 : h.c[k] & 0xffffu);
-            if (code - count < first) {
-                len_out = (uint32_t)len;
-                return (uint32_t)(index + (code - first));
-            }
-            index += count;
-            first += count;
-            first <<= 1;
-            code <<= 1;
-        }
+    for (int len = 1; len <= 15; len++) {
+        code |= (int32_t)(peek & 1u);
+        peek >>= 1;
+        const uint32_t word = h.c[(len - 1) >> 1];
+        const int32_t count = (int32_t)(((len - 1) & 1) ? word >> 16 : word & 0xffffu);
+        const bool hit = len_found == 0 && code - count < first;
+        at = hit ? (uint32_t)(index + (code - first)) : at;
+        len_found = hit ? (uint32_t)len : len_found;
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
     }
-    len_out = 0;
-    return 0;
+    len_out = len_found;
+    return at;
 }
 
-// Counting sort of `n` code lengths into canonical order (puff.c construct()). Returns 0 for a complete code, > 0 for an
-// incomplete one (bits left over), < 0 for an over-subscribed one. Every lane does the same thing to the same LDS words.
-ITXI_FN int32_t itxi_construct(ItxiLds &S, ItxiCodes &h, uint16_t *sym, const uint8_t *lens, uint32_t n, uint32_t &n_zero_or_one)
+// Counting sort of `n` code lengths (T.lens[base ..]) into canonical order (puff.c construct()). Returns 0 for a complete
+// code, > 0 for an incomplete one (bits left over), < 0 for an over-subscribed one.
+ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint16_t *sym, uint32_t base, uint32_t n, uint32_t &n_zero_or_one)
 {
+    (void)ln;
     uint32_t cnt[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cnt[i] = 0;
     for (uint32_t s = 0; s < n; s++) {
-        const uint32_t l = ITXI_UNI((uint32_t)lens[s]);
+        const uint32_t l = ITXI_AT(T.lens, base + s);
 #pragma unroll
         for (int i = 0; i < 16; i++) cnt[i] += (l == (uint32_t)i) ? 1u : 0u;
     }
@@ -143,15 +156,15 @@ ITXI_FN int32_t itxi_construct(ItxiLds &S, ItxiCodes &h, uint16_t *sym, const ui
     uint32_t o = 0;
 #pragma unroll
     for (int len = 1; len <= 15; len++) {
-        S.offs[len] = (uint16_t)o;
+        ITXI_AT(T.offs, len) = (uint16_t)o;
         o += cnt[len];
     }
     for (uint32_t s = 0; s < n; s++) {
-        const uint32_t l = ITXI_UNI((uint32_t)lens[s]);
+        const uint32_t l = ITXI_AT(T.lens, base + s);
         if (l != 0) {
-            const uint32_t at = ITXI_UNI((uint32_t)S.offs[l]);
-            sym[at] = (uint16_t)s;
-            S.offs[l] = (uint16_t)(at + 1u);
+            const uint32_t at = ITXI_AT(T.offs, l);
+            ITXI_AT(sym, at) = (uint16_t)s;
+            ITXI_AT(T.offs, l) = (uint16_t)(at + 1u);
         }
     }
 #pragma unroll
@@ -159,42 +172,16 @@ ITXI_FN int32_t itxi_construct(ItxiLds &S, ItxiCodes &h, uint16_t *sym, const ui
     return left;
 }
 
-struct ItxiOut {
-    uint8_t *g;                            // the whole output buffer
-    uint32_t g0, gend;                     // this block's bytes are g[g0, gend)
-    uint32_t gp;                           // next byte to produce
-    uint32_t fl;                           // bytes below this offset are written back
+// What pass 1 leaves for pass 2, per block: lit[0, n_lit) the literal bytes in stream order; tok[0, n_tok) the matches,
+// x = literals since the previous match | length << 16, y = distance; literals after the last match: n_lit - (sum of x's
+// low halves). A stored block's bytes are literals.
+struct ItxiTokens {
+    uint8_t *lit;
+    uint32_t *tok;                         // pairs (x, y)
+    uint32_t n_lit, n_tok;
 };
 
-// write back ring bytes [from, to): whole aligned stripes as words, ragged ends (a block's first and last bytes share
-// words with its neighbours, which other waves write) byte by byte
-ITXI_FN void itxi_writeback(ItxiLds &S, ItxiOut &o, uint32_t to, uint32_t lane)
-{
-    const uint8_t *ring8 = reinterpret_cast<const uint8_t *>(S.ring32);
-    uint32_t from = o.fl;
-    while (from < to) {
-        const uint32_t stop = (from | (ITXI_STRIPE - 1u)) + 1u;                    // end of the stripe `from` lies in
-        const uint32_t upto = stop < to ? stop : to;
-        if ((from & (ITXI_STRIPE - 1u)) == 0 && upto == stop) {
-            for (uint32_t k = lane; k < ITXI_STRIPE / 4; k += ITXI_WAVE)
-                reinterpret_cast<uint32_t *>(o.g)[(from >> 2) + k] = S.ring32[((from & ITXI_MASK) >> 2) + k];
-        } else {
-            for (uint32_t a = from + lane; a < upto; a += ITXI_WAVE) o.g[a] = ring8[a & ITXI_MASK];
-        }
-        from = upto;
-    }
-    o.fl = to;
-}
-
-// after gp moved: every stripe that is complete leaves
-ITXI_FN void itxi_flush_full(ItxiLds &S, ItxiOut &o, uint32_t lane)
-{
-    const uint32_t full = o.gp & ~(ITXI_STRIPE - 1u);
-    if (full > o.fl) itxi_writeback(S, o, full, lane);
-}
-
-ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos, uint32_t data_end, uint8_t *out, uint32_t g0, uint32_t usize,
-                       uint32_t lane)
+ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_words, uint32_t data_pos, uint32_t data_end, uint32_t usize, ItxiTokens &K)
 {
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -202,17 +189,13 @@ ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos
     static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     static const uint8_t clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-    uint8_t *ring8 = reinterpret_cast<uint8_t *>(S.ring32);
     ItxiIn in;
     in.w = comp_words;
     in.end = data_end;
     itxi_in_start(in, data_pos);
-    ItxiOut o;
-    o.g = out;
-    o.g0 = g0;
-    o.gend = g0 + usize;
-    o.gp = g0;
-    o.fl = g0;
+    uint32_t produced = 0;                 // bytes the tokens so far stand for
+    uint32_t n_lit = 0, n_tok = 0, run = 0;       // run: literals since the last match
+    K.n_lit = K.n_tok = 0;
     ItxiCodes lc, dc;
 
     for (;;) {                                                     // one DEFLATE block per turn; each consumes >= 3 bits
@@ -230,18 +213,12 @@ ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos
             if ((len ^ nlen) != 0xffffu) return ITXI_E_STORED;
             const uint32_t pos = in.ip * 4u - in.bn / 8u;          // byte position of the data (bn is a multiple of 8 here)
             if (pos + len > data_end) return ITXI_E_INPUT;
-            if (len > o.gend - o.gp) return ITXI_E_OUTPUT;
+            if (len > usize - produced) return ITXI_E_OUTPUT;
             const uint8_t *src = reinterpret_cast<const uint8_t *>(comp_words) + pos;
-            uint32_t done = 0;
-            while (done < len) {                                   // a stripe's worth at a time so the ring never laps itself
-                uint32_t n = len - done;
-                const uint32_t room = ITXI_STRIPE - (o.gp & (ITXI_STRIPE - 1u));
-                if (n > room) n = room;
-                for (uint32_t k = lane; k < n; k += ITXI_WAVE) ring8[(o.gp + k) & ITXI_MASK] = ITXI_LOADB(src, done + k);
-                o.gp += n;
-                done += n;
-                itxi_flush_full(S, o, lane);
-            }
+            for (uint32_t k = 0; k < len; k++) K.lit[n_lit + k] = ITXI_LOADB(src, k);
+            n_lit += len;
+            run += len;
+            produced += len;
             itxi_in_start(in, pos + len);
         } else if (type == 3) {
             return ITXI_E_BTYPE;
@@ -250,23 +227,23 @@ ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos
             if (type == 1) {
                 nl = 288;
                 nd = 30;
-                for (uint32_t s = lane; s < 288; s += ITXI_WAVE) S.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-                for (uint32_t s = lane; s < 30; s += ITXI_WAVE) S.lens[288 + s] = 5;
+                for (uint32_t s = 0; s < 288; s++) ITXI_AT(T.lens, s) = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
+                for (uint32_t s = 0; s < 30; s++) ITXI_AT(T.lens, 288 + s) = 5;
             } else {
                 itxi_refill(in);
                 nl = itxi_bits(in, 5) + 257u;
                 nd = itxi_bits(in, 5) + 1u;
                 const uint32_t nc = itxi_bits(in, 4) + 4u;
                 if (nl > 286u || nd > 30u) return ITXI_E_CODES;
-                for (uint32_t s = lane; s < 19; s += ITXI_WAVE) S.lens[320 + s] = 0;
+                for (uint32_t s = 0; s < 19; s++) ITXI_AT(T.lens, 320 + s) = 0;
                 for (uint32_t i = 0; i < nc; i++) {
                     itxi_refill(in);
-                    S.lens[320 + clorder[i]] = (uint8_t)itxi_bits(in, 3);
+                    ITXI_AT(T.lens, 320 + clorder[i]) = (uint8_t)itxi_bits(in, 3);
                 }
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
                 ItxiCodes cc;
-                uint32_t nz;
-                if (itxi_construct(S, cc, S.lsym, S.lens + 320, 19, nz) != 0) return ITXI_E_CODES;     // must be complete
+                uint32_t n01;
+                if (itxi_construct(T, ln, cc, T.lsym, 320, 19, n01) != 0) return ITXI_E_CODES;         // must be complete
                 // code lengths of the literal/length and distance codes, run-length coded as ONE sequence (a run may
                 // cross from one code into the other); entry idx of it lives at place(idx)
 #define ITXI_PLACE(i) ((i) < nl ? (i) : 288u + ((i) - nl))
@@ -277,15 +254,15 @@ ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos
                     const uint32_t at = itxi_decode(cc, (uint32_t)in.bb & 0x7fffu, cl);
                     if (cl == 0) return ITXI_E_SYMBOL;
                     itxi_bits(in, cl);
-                    const uint32_t sym = ITXI_UNI((uint32_t)S.lsym[at]);
+                    const uint32_t sym = ITXI_AT(T.lsym, at);
                     if (sym < 16) {
-                        S.lens[ITXI_PLACE(idx)] = (uint8_t)sym;
+                        ITXI_AT(T.lens, ITXI_PLACE(idx)) = (uint8_t)sym;
                         idx++;
                     } else {
                         uint32_t rep, val = 0;
                         if (sym == 16) {
                             if (idx == 0) return ITXI_E_CODES;
-                            val = ITXI_UNI((uint32_t)S.lens[ITXI_PLACE(idx - 1)]);
+                            val = ITXI_AT(T.lens, ITXI_PLACE(idx - 1));
                             rep = 3u + itxi_bits(in, 2);
                         } else if (sym == 17) {
                             rep = 3u + itxi_bits(in, 3);
@@ -293,19 +270,19 @@ ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos
                             rep = 11u + itxi_bits(in, 7);
                         }
                         if (idx + rep > nl + nd) return ITXI_E_CODES;
-                        for (uint32_t k = lane; k < rep; k += ITXI_WAVE) S.lens[ITXI_PLACE(idx + k)] = (uint8_t)val;
+                        for (uint32_t k = 0; k < rep; k++) ITXI_AT(T.lens, ITXI_PLACE(idx + k)) = (uint8_t)val;
                         idx += rep;
                     }
                     if (itxi_overrun(in)) return ITXI_E_INPUT;
                 }
 #undef ITXI_PLACE
-                if (ITXI_UNI((uint32_t)S.lens[256]) == 0) return ITXI_E_CODES;                   // no end-of-block code
+                if (ITXI_AT(T.lens, 256) == 0) return ITXI_E_CODES;                              // no end-of-block code
             }
-            uint32_t nz;
-            int32_t left = itxi_construct(S, lc, S.lsym, S.lens, nl, nz);
-            if (type == 2 && left != 0 && (left < 0 || nl != nz)) return ITXI_E_CODES;           // the fixed code is incomplete by definition
-            left = itxi_construct(S, dc, S.dsym, S.lens + 288, nd, nz);
-            if (type == 2 && left != 0 && (left < 0 || nd != nz)) return ITXI_E_CODES;
+            uint32_t n01;
+            int32_t left = itxi_construct(T, ln, lc, T.lsym, 0, nl, n01);
+            if (type == 2 && left != 0 && (left < 0 || nl != n01)) return ITXI_E_CODES;          // the fixed code is incomplete by definition
+            left = itxi_construct(T, ln, dc, T.dsym, 288, nd, n01);
+            if (type == 2 && left != 0 && (left < 0 || nd != n01)) return ITXI_E_CODES;
 
             for (;;) {                                             // one symbol per turn; each produces output or ends the block
                 itxi_refill(in);
@@ -313,15 +290,13 @@ ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos
                 uint32_t at = itxi_decode(lc, (uint32_t)in.bb & 0x7fffu, cl);
                 if (cl == 0) return ITXI_E_SYMBOL;
                 itxi_bits(in, cl);
-                const uint32_t sym = ITXI_UNI((uint32_t)S.lsym[at]);
+                const uint32_t sym = ITXI_AT(T.lsym, at);
                 if (sym < 256u) {
-                    if (o.gp >= o.gend) return ITXI_E_OUTPUT;
-                    if (lane == 0) ring8[o.gp & ITXI_MASK] = (uint8_t)sym;
-                    o.gp++;
-                    if ((o.gp & (ITXI_STRIPE - 1u)) == 0) {
-                        if (itxi_overrun(in)) return ITXI_E_INPUT;
-                        itxi_flush_full(S, o, lane);
-                    }
+                    if (produced >= usize) return ITXI_E_OUTPUT;
+                    K.lit[n_lit] = (uint8_t)sym;
+                    n_lit++;
+                    run++;
+                    produced++;
                     continue;
                 }
                 if (sym == 256u) break;
@@ -332,44 +307,176 @@ ITXI_FN int itxi_block(ItxiLds &S, const uint32_t *comp_words, uint32_t data_pos
                 at = itxi_decode(dc, (uint32_t)in.bb & 0x7fffu, cl);
                 if (cl == 0) return ITXI_E_SYMBOL;
                 itxi_bits(in, cl);
-                const uint32_t di = ITXI_UNI((uint32_t)S.dsym[at]);
+                const uint32_t di = ITXI_AT(T.dsym, at);
                 if (di >= 30u) return ITXI_E_SYMBOL;
                 const uint32_t dist = dbase[di] + itxi_bits(in, dext[di]);
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
-                if (dist > o.gp - o.g0) return ITXI_E_DIST;
-                if (len > o.gend - o.gp) return ITXI_E_OUTPUT;
-                const uint32_t src0 = o.gp - dist;
-                if (dist <= ITXI_NEAR) {
-                    if (dist >= 64u || dist >= len) {             // 64: the widest step any build takes
-                        // a step's sources were all written before the step (earlier steps or earlier symbols)
-                        for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
-                            const uint32_t k = k0 + lane;
-                            if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k) & ITXI_MASK];
-                        }
-                    } else {
-                        // the match overlaps itself within a step: the output is the last `dist` bytes repeated
-                        for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
-                            const uint32_t k = k0 + lane;
-                            if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k % dist) & ITXI_MASK];
-                        }
-                    }
-                } else {
-                    // further back than the ring reaches: those bytes left in whole stripes long ago (dist > 7 KiB > len)
-                    ITXI_FENCE();
-                    for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
-                        const uint32_t k = k0 + lane;
-                        if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ITXI_LOADB(o.g, src0 + k);
-                    }
-                }
-                o.gp += len;
-                itxi_flush_full(S, o, lane);
+                if (dist > produced) return ITXI_E_DIST;
+                if (len > usize - produced) return ITXI_E_OUTPUT;
+                K.tok[2 * n_tok] = run | (len << 16);
+                K.tok[2 * n_tok + 1] = dist;
+                n_tok++;
+                run = 0;
+                produced += len;
             }
         }
-        if (last) break;
         if (itxi_overrun(in)) return ITXI_E_INPUT;
+        if (last) break;
     }
-    if (itxi_overrun(in)) return ITXI_E_INPUT;
-    if (o.gp != o.gend) return ITXI_E_OUTPUT;
-    itxi_writeback(S, o, o.gend, lane);
+    if (produced != usize) return ITXI_E_OUTPUT;
+    K.n_lit = n_lit;
+    K.n_tok = n_tok;
+    return ITXI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- pass 2: bytes
+
+struct ItxiOut {
+    uint8_t *g;                            // the whole output buffer
+    uint32_t g0, gend;                     // this block's bytes are g[g0, gend)
+    uint32_t gp;                           // next byte to produce
+    uint32_t fl;                           // bytes below this offset are written back
+};
+
+// write back ring bytes [fl, to): whole aligned stripes as words, ragged ends (a block's first and last bytes share
+// words with its neighbours, which other waves write) byte by byte
+ITXI_FN void itxi_writeback(const uint32_t *ring32, ItxiOut &o, uint32_t to, uint32_t lane)
+{
+    const uint8_t *ring8 = reinterpret_cast<const uint8_t *>(ring32);
+    uint32_t from = o.fl;
+    while (from < to) {
+        const uint32_t stop = (from | (ITXI_STRIPE - 1u)) + 1u;                    // end of the stripe `from` lies in
+        const uint32_t upto = stop < to ? stop : to;
+        if ((from & (ITXI_STRIPE - 1u)) == 0 && upto == stop) {
+            for (uint32_t k = lane; k < ITXI_STRIPE / 4; k += ITXI_WAVE)
+                reinterpret_cast<uint32_t *>(o.g)[(from >> 2) + k] = ring32[((from & ITXI_MASK) >> 2) + k];
+        } else {
+            for (uint32_t a = from + lane; a < upto; a += ITXI_WAVE) o.g[a] = ring8[a & ITXI_MASK];
+        }
+        from = upto;
+    }
+    o.fl = to;
+}
+
+// after gp moved: every stripe that is complete leaves
+ITXI_FN void itxi_flush_full(const uint32_t *ring32, ItxiOut &o, uint32_t lane)
+{
+    const uint32_t full = o.gp & ~(ITXI_STRIPE - 1u);
+    if (full > o.fl) itxi_writeback(ring32, o, full, lane);
+}
+
+#define ITXI_LSTAGE 4096u                  // pass 2: literal bytes staged in LDS per refill (16 bytes per lane and load)
+
+struct ItxiLit {
+    const uint8_t *lit;                    // the block's literal string (16-byte aligned)
+    uint32_t *stage32;                     // LDS, ITXI_LSTAGE bytes
+    uint32_t base, n_lit;                  // stage32 holds lit[base, base + ITXI_LSTAGE) as far as it exists; base % 16 == 0
+};
+
+// n literal bytes lit[lp, lp + n) into the ring, a stripe's worth at a time so the ring never laps itself. The literals
+// come through an LDS stage refilled 4 KiB at a time: one global round trip per few hundred tokens instead of one each.
+ITXI_FN void itxi_literals(uint32_t *ring32, ItxiOut &o, ItxiLit &L, uint32_t lp, uint32_t n, uint32_t lane)
+{
+    uint8_t *ring8 = reinterpret_cast<uint8_t *>(ring32);
+    const uint8_t *stage8 = reinterpret_cast<const uint8_t *>(L.stage32);
+    uint32_t done = 0;
+    while (done < n) {
+        uint32_t m = n - done;
+        const uint32_t room = ITXI_STRIPE - (o.gp & (ITXI_STRIPE - 1u));
+        if (m > room) m = room;
+        const uint32_t at = lp + done;
+        if (at < L.base || at + m > L.base + ITXI_LSTAGE) {
+            L.base = at & ~15u;
+            uint32_t have = L.n_lit - L.base;                      // at < n_lit: there is something to stage
+            if (have > ITXI_LSTAGE) have = ITXI_LSTAGE;
+            for (uint32_t k = lane * 16u; k < have; k += ITXI_WAVE * 16u) {        // reads up to 15 bytes past n_lit: inside the block's scratch
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(L.lit + L.base + k);
+                const uint32_t a = ITXI_LOADW(src, 0), b = ITXI_LOADW(src, 1), c = ITXI_LOADW(src, 2), d = ITXI_LOADW(src, 3);
+                L.stage32[k / 4] = a;
+                L.stage32[k / 4 + 1] = b;
+                L.stage32[k / 4 + 2] = c;
+                L.stage32[k / 4 + 3] = d;
+            }
+        }
+        for (uint32_t k = lane; k < m; k += ITXI_WAVE) ring8[(o.gp + k) & ITXI_MASK] = stage8[at - L.base + k];
+        o.gp += m;
+        done += m;
+        itxi_flush_full(ring32, o, lane);
+    }
+}
+
+// Replays a block's tokens (validated by pass 1: distances inside the block, lengths inside usize) into out[g0, g0 + usize).
+// Tokens are fetched a wave's width at a time, one per lane, the next batch while the current one is replayed.
+ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit, const uint32_t *tok, uint32_t n_lit, uint32_t n_tok, uint8_t *out, uint32_t g0,
+                         uint32_t usize, uint32_t lane)
+{
+    uint8_t *ring8 = reinterpret_cast<uint8_t *>(ring32);
+    ItxiOut o;
+    o.g = out;
+    o.g0 = g0;
+    o.gend = g0 + usize;
+    o.gp = g0;
+    o.fl = g0;
+    ItxiLit L;
+    L.lit = lit;
+    L.stage32 = stage32;
+    L.base = 0xfffff000u;                                          // nothing staged yet
+    L.n_lit = n_lit;
+    uint32_t lp = 0;
+    if (n_lit > usize || n_tok > ITXI_MAX_TOK) return ITXI_E_OUTPUT;
+    uint32_t nx = 0, nd = 0;
+    if (lane < n_tok) {
+        nx = ITXI_LOADW(tok, 2 * lane);
+        nd = ITXI_LOADW(tok, 2 * lane + 1);
+    }
+    for (uint32_t t0 = 0; t0 < n_tok; t0 += ITXI_WAVE) {
+        const uint32_t cx = nx, cd = nd;
+        const uint32_t tn = t0 + ITXI_WAVE + lane;
+        if (tn < n_tok) {
+            nx = ITXI_LOADW(tok, 2 * tn);
+            nd = ITXI_LOADW(tok, 2 * tn + 1);
+        }
+        const uint32_t nb = n_tok - t0 < ITXI_WAVE ? n_tok - t0 : ITXI_WAVE;
+        for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t x = ITXI_BCAST(cx, j), dist = ITXI_BCAST(cd, j);
+            const uint32_t run = x & 0xffffu, len = x >> 16;
+            // guards that hold for every token pass 1 lets through; they keep a damaged token array from leaving the block
+            if (run > n_lit - lp || run + len > o.gend - o.gp || len < 3u || len > 258u) return ITXI_E_OUTPUT;
+            if (run) {
+                itxi_literals(ring32, o, L, lp, run, lane);
+                lp += run;
+            }
+            if (dist == 0 || dist > o.gp - o.g0) return ITXI_E_DIST;
+            const uint32_t src0 = o.gp - dist;
+            if (dist <= ITXI_NEAR) {
+                if (dist >= 64u || dist >= len) {             // 64: the widest step any build takes
+                    // a step's sources were all written before the step (earlier steps or earlier tokens)
+                    for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
+                        const uint32_t k = k0 + lane;
+                        if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k) & ITXI_MASK];
+                    }
+                } else {
+                    // the match overlaps itself within a step: the output is the last `dist` bytes repeated
+                    for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
+                        const uint32_t k = k0 + lane;
+                        if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k % dist) & ITXI_MASK];
+                    }
+                }
+            } else {
+                // further back than the ring reaches: those bytes left in whole stripes long ago (dist > 7 KiB > len)
+                ITXI_FENCE();
+                for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
+                    const uint32_t k = k0 + lane;
+                    if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ITXI_LOADB(o.g, src0 + k);
+                }
+            }
+            o.gp += len;
+            itxi_flush_full(ring32, o, lane);
+        }
+    }
+    const uint32_t tail = n_lit - lp;
+    if (tail != o.gend - o.gp) return ITXI_E_OUTPUT;
+    if (tail) itxi_literals(ring32, o, L, lp, tail, lane);
+    itxi_writeback(ring32, o, o.gend, lane);
     return ITXI_OK;
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "itx_engine_staging", "itx_engine_submit_slot", "itx_engine_classify_slot", "itx_engine_wait_slot", "itx_engine_submit_device",
     "itx_engine_classify_device", "itx_engine_first_hit_slot", "itx_engine_first_hit_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
     "itx_engine_partial_size", "itx_engine_export_partial", "itx_engine_finish_partial",
-    "itx_inflater_create", "itx_inflater_destroy", "itx_inflate_bgzf", "itx_pinned_alloc", "itx_pinned_free",
+    "itx_inflater_create", "itx_inflater_destroy", "itx_inflate_bgzf", "itx_inflater_last_ms", "itx_pinned_alloc", "itx_pinned_free",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.itx_inflater_destroy.argtypes = [C.c_void_p]
     L.itx_inflater_destroy.restype = None
     L.itx_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.itx_inflater_last_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.itx_pinned_alloc.argtypes = [C.c_size_t]
     L.itx_pinned_alloc.restype = C.c_void_p
     L.itx_pinned_free.argtypes = [C.c_void_p]

@@ -59,6 +59,9 @@ struct aln_reader {
     int eof;                  /* no more compressed input (end of file or a damaged block)                     */
     struct blk *blk;          /* block index of the chunk being inflated                                        */
     size_t blk_cap;
+    itx_bgzf_block *dblk;     /* the same for the device inflater, and its per-block verdicts                   */
+    uint8_t *dstatus;
+    size_t dblk_cap;
     /* read-ahead (bgzf_load_chunk): spare buffer the loader thread inflates the next chunk into */
     uint8_t *nbuf;
     size_t ncap, nlen;
@@ -74,7 +77,38 @@ struct aln_reader {
 };
 
 /* ---- BGZF ------------------------------------------------------------------------------------------------ */
+static aln_device_inflate dev_inflate;       /* .inflate == NULL: the host's threads inflate */
+void aln_use_device_inflate(const aln_device_inflate *ops)
+{
+    if (ops) dev_inflate = *ops;
+    else memset(&dev_inflate, 0, sizeof dev_inflate);
+}
+
+/* the big byte buffers (compressed chunks, inflated chunks): page-locked when the device inflates */
+static uint8_t *buf_alloc(size_t n)
+{
+    if (dev_inflate.alloc) {
+        uint8_t *p = dev_inflate.alloc(n);
+        if (!p) die("cannot get %zu bytes of page-locked memory", n);
+        return p;
+    }
+    return xmalloc(n);
+}
+static void buf_free(uint8_t *p)
+{
+    if (!p) return;
+    if (dev_inflate.release) dev_inflate.release(p);
+    else free(p);
+}
+static uint8_t *buf_grow(uint8_t *old, size_t keep, size_t ncap)
+{
+    uint8_t *p = buf_alloc(ncap);
+    if (old && keep) memcpy(p, old, keep);
+    buf_free(old);
+    return p;
+}
 #define CHUNK_COMPRESSED_DEFAULT (48u << 20)
+#define CHUNK_COMPRESSED_DEVICE (128u << 20)     /* a lane per block on the device: it takes thousands of blocks to fill it */
 /* compressed bytes read and inflated per step; ITX_BGZF_CHUNK overrides it (tests force many small steps) */
 static size_t chunk_compressed(void)
 {
@@ -82,7 +116,7 @@ static size_t chunk_compressed(void)
     if (!v) {
         const char *e = getenv("ITX_BGZF_CHUNK");
         const long x = e ? atol(e) : 0;
-        v = x >= 1 ? (size_t)x : CHUNK_COMPRESSED_DEFAULT;
+        v = x >= 1 ? (size_t)x : dev_inflate.inflate ? CHUNK_COMPRESSED_DEVICE : CHUNK_COMPRESSED_DEFAULT;
     }
     return v;
 }
@@ -166,7 +200,7 @@ static size_t raw_next(aln_reader *r)
 {
     if (r->io_done) return 0;
     if (!r->io_on) {
-        for (int k = 0; k < 2; k++) r->craw[k] = xmalloc(RAW_HEAD + RAW_STEP + 64);
+        for (int k = 0; k < 2; k++) r->craw[k] = buf_alloc(RAW_HEAD + RAW_STEP + 64);
         pthread_mutex_init(&r->io_mu, NULL);
         pthread_cond_init(&r->io_cv, NULL);
         r->io_buf = 0;
@@ -238,17 +272,40 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
         off += bsize;
     }
     if (at + utot + 64 > *pcap) {
+        const size_t old_cap = *pcap;
         *pcap = (at + utot) * 5 / 4 + BGZF_MAX + 64;
-        *pbuf = xrealloc(*pbuf, *pcap);
+        *pbuf = buf_grow(*pbuf, at < old_cap ? at : old_cap, *pcap);      /* the bytes before `at` are the caller's */
     }
     tq = now_s();
     int bad = 0;
     uint8_t *dst0 = *pbuf + at;
     const struct blk *blocks = bl;
     const uint8_t *cbase = r->cbuf;
+    if (dev_inflate.inflate && nb) {
+        /* the device takes the whole chunk: one wavefront lane per block for the Huffman half, one wave per block for the
+         * copies (csrc/itx_inflate.hip). A block it flags is looked at again by zlib below, whose verdict is the reference's. */
+        if (r->dblk_cap < nb) {
+            r->dblk_cap = nb + nb / 4;
+            r->dblk = xrealloc(r->dblk, sizeof *r->dblk * r->dblk_cap);
+            r->dstatus = xrealloc(r->dstatus, r->dblk_cap);
+        }
+        for (size_t i = 0; i < nb; i++) {
+            r->dblk[i].coff = (uint32_t)bl[i].coff;
+            r->dblk[i].csize = (uint32_t)bl[i].csize;
+            r->dblk[i].uoff = (uint32_t)bl[i].uoff;
+            r->dblk[i].usize = (uint32_t)bl[i].usize;
+        }
+        if (dev_inflate.inflate(dev_inflate.ctx, cbase, off, r->dblk, nb, dst0, utot, r->dstatus) != 0) die("the device inflater failed (HIP error)");
+        for (size_t i = 0; i < nb; i++)
+            if (r->dstatus[i] && blocks[i].usize) {
+                if (inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
+                else fprintf(stderr, "[iteres] note: BGZF block at chunk offset %zu declined by the device decoder (code %d), inflated by zlib\n", blocks[i].coff, r->dstatus[i]);
+            }
+    } else {
 #pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
-    for (long i = 0; i < (long)nb; i++)
-        if (blocks[i].usize && inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
+        for (long i = 0; i < (long)nb; i++)
+            if (blocks[i].usize && inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
+    }
     t_inflate += now_s() - tq;
     if (bad) {
         /* a block that does not inflate ends the stream there, like bgzf_read returning an error (bgzf.c:471-521) */
@@ -333,10 +390,10 @@ static size_t bgzf_load_chunk(aln_reader *r)
     pthread_mutex_unlock(&r->pf_mu);
     const size_t tail = r->ulen - r->upos, n = r->nlen;
     if (tail > PF_HEAD) {                                      /* a record of more than 4 MB: make room the slow way */
-        uint8_t *big = xmalloc(tail + n + 64);
+        uint8_t *big = buf_alloc(tail + n + 64);
         memcpy(big, r->ubuf + r->upos, tail);
         memcpy(big + tail, r->nbuf + PF_HEAD, n);
-        free(r->ubuf);
+        buf_free(r->ubuf);
         r->ubuf = big;
         r->ucap = tail + n + 64;
         r->upos = 0;
@@ -498,14 +555,16 @@ void aln_close(aln_reader *r)
         pthread_join(r->io_thread, NULL);
     }
     if (r->f) fclose(r->f);
-    free(r->craw[0]);
-    free(r->craw[1]);
-    free(r->nbuf);
+    buf_free(r->craw[0]);
+    buf_free(r->craw[1]);
+    buf_free(r->nbuf);
     free(r->blk);
+    free(r->dblk);
+    free(r->dstatus);
     for (int i = 0; i < r->n_targets; i++) free(r->tname[i]);
     free(r->tname);
     names_free(&r->tnames);
-    free(r->ubuf);
+    buf_free(r->ubuf);
     free(r->rec_off);
     free(r->spec);
     free(r->line);

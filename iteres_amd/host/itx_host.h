@@ -68,6 +68,16 @@ void rmsk_free(rmsk_t *r);
 
 /* ---- alignment input: BAM (BGZF) or SAM text, decoded into the engine's record SoA */
 typedef struct aln_reader aln_reader;
+/* BGZF blocks inflated on the device (include/iteres_amd.h: itx_inflate_bgzf) instead of by the host's threads. The
+ * reader stays free of any link-time dependency on the HIP library: the driver hands it these entry points before it
+ * opens a file. `alloc` / `release`: page-locked memory for the buffers that cross PCIe. NULL restores host inflate. */
+typedef struct aln_device_inflate {
+    void *ctx;
+    int (*inflate)(void *ctx, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, void *out, size_t out_len, uint8_t *status);
+    void *(*alloc)(size_t bytes);
+    void (*release)(void *p);
+} aln_device_inflate;
+void aln_use_device_inflate(const aln_device_inflate *ops);
 aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the file cannot be opened / has no header */
 void aln_close(aln_reader *r);
 int aln_n_targets(const aln_reader *r);
@@ -119,7 +129,8 @@ char *filename_without_ext(const char *path);
 /* Runs the record loop (generic.c:700-1062 / 343-697) over one or more files through the engine.
  * progress_every: 100000 (stat, generic.c:760) or 10000 (filter, generic.c:397). want_qnames: per-locus read
  * names (filter -r): *locus_names[row] receives a comma-joined list in BAM order. */
-void gpu_warmup_start(void);      /* starts the HIP runtime on a helper thread; run_stream joins it */
+void gpu_warmup_start(int bam_input);  /* starts the HIP runtime on a helper thread (and, for BAM input, the device inflater with its
+                                        * page-locked buffers); run_stream joins it */
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
                 unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names,
                 host_counts *hc);

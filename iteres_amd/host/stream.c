@@ -25,20 +25,64 @@ static double now_s(void)
  * thread parses the rmsk file. */
 #include <pthread.h>
 static pthread_t warm_thread;
-static int warm_on;
+static int warm_on, warm_bam;
+
+/* BGZF blocks are inflated on the device (include/iteres_amd.h: itx_inflate_bgzf) unless ITX_HOST_INFLATE is set. The
+ * reader's big buffers then have to be page-locked, and locking a gigabyte takes a good fraction of a second: the helper
+ * thread gets them ready while the main thread parses the rmsk file, and hands them out from this little pool. */
+static itx_inflater *g_inflater;
+#define POOL_N 4
+static struct { void *p; size_t cap; int used; } pool[POOL_N];
+static pthread_mutex_t pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static void *pool_alloc(size_t n)
+{
+    pthread_mutex_lock(&pool_mu);
+    int best = -1;
+    for (int i = 0; i < POOL_N; i++)
+        if (pool[i].p && !pool[i].used && pool[i].cap >= n && (best < 0 || pool[i].cap < pool[best].cap)) best = i;
+    if (best >= 0) pool[best].used = 1;
+    pthread_mutex_unlock(&pool_mu);
+    return best >= 0 ? pool[best].p : itx_pinned_alloc(n);
+}
+static void pool_release(void *p)
+{
+    pthread_mutex_lock(&pool_mu);
+    for (int i = 0; i < POOL_N; i++)
+        if (pool[i].p == p) {
+            pool[i].used = 0;                                        /* stays locked for the next file */
+            pthread_mutex_unlock(&pool_mu);
+            return;
+        }
+    pthread_mutex_unlock(&pool_mu);
+    itx_pinned_free(p);
+}
+static int dev_inflate_call(void *ctx, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, void *out, size_t out_len, uint8_t *status)
+{
+    return itx_inflate_bgzf((itx_inflater *)ctx, comp, comp_len, blk, n_blk, out, out_len, status);
+}
+
 static void *warm_main(void *arg)
 {
     (void)arg;
-    struct timespec a, b;
-    clock_gettime(CLOCK_MONOTONIC, &a);
-    (void)itx_device_count();
-    clock_gettime(CLOCK_MONOTONIC, &b);
+    const double a = now_s();
+    const int ndev = itx_device_count();
+    const double b = now_s();
+    if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(0, &g_inflater) == ITX_OK) {
+        /* two compressed chunks and two inflated ones (a BAM inflates about four- to fivefold; the reader grows what
+         * turns out too small) */
+        static const size_t want[POOL_N] = {(128u << 20) + (1u << 17), (128u << 20) + (1u << 17), 800u << 20, 800u << 20};
+        for (int i = 0; i < POOL_N; i++) {
+            pool[i].p = itx_pinned_alloc(want[i]);
+            pool[i].cap = pool[i].p ? want[i] : 0;
+        }
+    }
     if (getenv("ITX_TIMING"))
-        fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s (helper thread)\n", (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec));
+        fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s, device inflater + page-locked buffers %.3f s (helper thread)\n", b - a, now_s() - b);
     return NULL;
 }
-void gpu_warmup_start(void)
+void gpu_warmup_start(int bam_input)
 {
+    warm_bam = bam_input;
     if (!warm_on && pthread_create(&warm_thread, NULL, warm_main, NULL) == 0) warm_on = 1;
 }
 static void gpu_warmup_join(void)
@@ -121,6 +165,10 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     int ndev = itx_device_count();
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
+    if (g_inflater) {
+        const aln_device_inflate ops = {g_inflater, dev_inflate_call, pool_alloc, pool_release};
+        aln_use_device_inflate(&ops);
+    }
     /* table: every chromosome of the size file is known to the engine (a read may land on one without repeats) */
     const uint32_t n_chrom = chr_sizes->names.n;
     itx_table *tab = NULL;

@@ -1,16 +1,33 @@
-// Host build of the wave's DEFLATE decoder (iteres_amd/csrc/itx_inflate_core.h) with a one-lane "wave": test
-// infrastructure only — the CPU suite fuzzes the decoder's logic against zlib here before it ever runs on a GPU.
+// Host build of the device DEFLATE decoder (iteres_amd/csrc/itx_inflate_core.h) with a one-lane "wave" and plain
+// arrays for the per-decoder tables: test infrastructure only — the CPU suite fuzzes both passes against zlib here
+// before they ever run on a GPU.
 #include <stdint.h>
+#include <vector>
 #define ITXI_WAVE 1u
 #define ITXI_FN static inline
 #define ITXI_UNI(x) (x)
+#define ITXI_BCAST(v, j) (v)
+#define ITXI_AT(p, i) (p)[(i)]
 #define ITXI_LOADW(w, i) ((w)[i])
 #define ITXI_LOADB(p, i) ((p)[i])
 #define ITXI_FENCE() ((void)0)
 #include "../iteres_amd/csrc/itx_inflate_core.h"
 
-extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, uint32_t data_end, uint8_t *out, uint32_t g0, uint32_t usize)
+extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, uint32_t data_end, uint8_t *out, uint32_t g0, uint32_t usize,
+                                uint32_t *n_lit, uint32_t *n_tok)
 {
-    static thread_local ItxiLds S;
-    return itxi_block(S, comp_words, data_pos, data_end, out, g0, usize, 0);
+    static thread_local uint16_t lsym[288], dsym[32], offs[16];
+    static thread_local uint8_t lens[352];
+    static thread_local uint32_t ring32[ITXI_RING / 4], stage32[ITXI_LSTAGE / 4];
+    static thread_local std::vector<uint32_t> lit32(ITXI_MAX_BLOCK / 4 + 4);
+    uint8_t *lit = reinterpret_cast<uint8_t *>(lit32.data());
+    static thread_local std::vector<uint32_t> tok(2 * ITXI_MAX_TOK);
+    if (usize > ITXI_MAX_BLOCK) return ITXI_E_OUTPUT;
+    ItxiTab T{lsym, dsym, offs, lens};
+    ItxiTokens K{lit, tok.data(), 0, 0};
+    int rc = itxi_tokens(T, 0, comp_words, data_pos, data_end, usize, K);
+    if (n_lit) *n_lit = K.n_lit;
+    if (n_tok) *n_tok = K.n_tok;
+    if (rc != ITXI_OK) return rc;
+    return itxi_resolve(ring32, stage32, lit, tok.data(), K.n_lit, K.n_tok, out, g0, usize, 0);
 }

@@ -60,3 +60,27 @@ def test_cli_matches_reference_files(case, run_name, exe, tmp_path):
     else:
         for banner in ("* Start to parse the rmsk file", "* Start to parse the SAM/BAM file", "* Preparing the output file", "* Done, time used"):
             assert banner in err
+
+
+@pytest.mark.parametrize("env", [{"ITX_BGZF_CHUNK": "30000", "ITX_HOP_PIECE": "500"}, {"ITX_BGZF_CHUNK": "3000"}, {"ITX_HOST_INFLATE": "1"},
+                                 {"ITX_HOST_INFLATE": "1", "ITX_BGZF_CHUNK": "30000"}])
+def test_cli_decode_paths_agree(env, exe, tmp_path):
+    """The decode side of the drop-in has several routes — BGZF blocks inflated on the device (default) or by the host's
+    threads, the file taken in one chunk or in hundreds (carry-over of partial blocks and records, buffer swaps), records
+    located in pieces — and every one of them must produce the reference's files."""
+    for case, run_name in (("mid", "stat_default"), ("sidechan", "stat_veto"), ("sidechan", "filter_R")):
+        run = gc.manifest_run(case, run_name)
+        if not run["aln"].endswith(".bam"):
+            continue
+        src = os.path.join(gc.GOLDEN, case, "in")
+        d = tmp_path / f"{case}_{run_name}"
+        d.mkdir()
+        paths = [refio.materialise(src, n, str(d)) for n in ["chrom.sizes", "rep.sizes", "rmsk.txt", run["aln"]]]
+        work = d / "out"
+        work.mkdir()
+        pr = subprocess.run([exe, run["cmd"]] + run["opts"] + ["-o", run["prefix"]] + paths, cwd=work, capture_output=True, text=True, timeout=600,
+                            env=dict(os.environ, **env))
+        assert pr.returncode == run["rc"], pr.stderr[-2000:]
+        for fn in run["files"]:
+            want = refio.read_bytes(os.path.join(gc.GOLDEN, case, run_name, fn))
+            assert (work / fn).read_bytes() == want, f"{env}: {case}/{run_name}/{fn} differs"

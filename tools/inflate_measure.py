@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Scratch measurement: itx_inflate_bgzf on a synthetic BAM (tools/mkbam.c), whole call and kernel-only, next to zlib
 on one host core.   python tools/inflate_measure.py [n_reads=2000000] [seq_len=100] [repeat=3]"""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -30,7 +31,6 @@ def main():
     print(f"{len(comp) / 1e6:.1f} MB compressed, {total / 1e6:.1f} MB inflated, {len(blocks)} blocks", flush=True)
     L = eng.load()
     h = eng.Inflater()
-    import ctypes as C
     cp = L.itx_pinned_alloc(len(comp) + 64)
     op = L.itx_pinned_alloc(total + 64)
     C.memmove(cp, comp, len(comp))
@@ -39,7 +39,9 @@ def main():
         t0 = time.perf_counter()
         eng._chk(L.itx_inflate_bgzf(h._h, cp, len(comp), eng._p(blocks), len(blocks), op, total, eng._p(status)), "inflate")
         dt = time.perf_counter() - t0
-        print(f"call {it}: {dt * 1e3:.1f} ms -> {total / dt / 1e9:.2f} GB/s inflated, bad blocks {int((status != 0).sum())}", flush=True)
+        a, b = C.c_float(), C.c_float()
+        L.itx_inflater_last_ms(h._h, C.byref(a), C.byref(b))
+        print(f"call {it}: {dt * 1e3:.1f} ms -> {total / dt / 1e9:.2f} GB/s inflated (pass 1 {a.value:.2f} ms, pass 2 first group {b.value:.2f} ms), bad blocks {int((status != 0).sum())}", flush=True)
     out = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(total,))
     t0 = time.perf_counter()
     nchk = min(len(blocks), 400)

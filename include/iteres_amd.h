@@ -228,6 +228,36 @@ int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_len, const i
                      uint8_t *status);
 /* Device time of the two passes of the last call (Huffman -> tokens; first group of tokens -> bytes), milliseconds. */
 int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve_ms);
+
+/* ---- BAM records located and parsed on the device ---------------------------------------------------------------
+ * Replaces bam_read1 (cussamtools/bam.c:179-210) and the field reads of the scan loop (generic.c:745-905 off
+ * bam1_core_t, bam.h:169-177; bam_calend bam.c:17-27) for whole chunks: the inflated bytes never leave the device,
+ * only the per-record SoA (the itx_staging arrays) comes back. An inflater holds two WINDOWS of inflated bytes (w = 0,
+ * 1) so that one can be filled while the records of the other are still being fetched:
+ *   push      inflate the blocks of a chunk into window w (offsets as for itx_inflate_bgzf; *n_new = bytes added)
+ *   patch     overwrite part of what push produced (a block the caller inflated itself); truncate: drop the end
+ *   carry     move the unconsumed tail of window `from` (a partial record) in front of window `to`'s fresh bytes
+ *   peek/skip the unconsumed bytes from the front (the BAM header is parsed by the caller)
+ *   parse     locate every complete record of window w and parse it: *n_rec records; *malformed = a record length
+ *             below 32 ended the stream (bam.c:186-190); *flags bit 0: some record has PAIRED set, bit 1: some
+ *             record carries an XA tag; *rewalked: pieces whose guessed start had to be corrected (may be NULL)
+ *   fetch     records [first, first + n) of the last parse into dst's HOST arrays at index dst_at (hit_row untouched),
+ *             optionally their byte offsets in the window and per-record XA marks
+ *   bytes     raw window bytes at such offsets (read names, XA / NM strings: the caller's side channels)
+ * Records are located by guess-and-verify (csrc/itx_inflate.hip): exact whatever the bytes look like. A record of
+ * more than 4 MiB that straddles two chunks is beyond this path (ITX_E_LIMIT). One thread may push while another
+ * parses / fetches the OTHER window. */
+int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, uint8_t *status, size_t *n_new);
+int itx_bamwin_patch(itx_inflater *h, int w, size_t uoff, const void *bytes, size_t len);
+int itx_bamwin_truncate(itx_inflater *h, int w, size_t n_new);
+int itx_bamwin_carry(itx_inflater *h, int from, int to);
+int itx_bamwin_avail(const itx_inflater *h, int w, size_t *bytes);
+int itx_bamwin_peek(itx_inflater *h, int w, size_t off, void *dst, size_t len);
+int itx_bamwin_skip(itx_inflater *h, int w, size_t n);
+int itx_bamwin_parse(itx_inflater *h, int w, int n_targets, size_t *n_rec, int *malformed, int *flags, size_t *rewalked);
+int itx_bamwin_fetch(itx_inflater *h, size_t first, size_t n, const itx_staging *dst, size_t dst_at, uint32_t *rec_off, uint8_t *xa);
+int itx_bamwin_bytes(itx_inflater *h, size_t off, void *dst, size_t len);
+
 /* Page-locked host memory for the buffers that cross PCIe on every call (NULL when it cannot be had). */
 void *itx_pinned_alloc(size_t bytes);
 void itx_pinned_free(void *p);

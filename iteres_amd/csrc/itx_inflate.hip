@@ -63,6 +63,194 @@ __global__ __launch_bounds__(64) void k_resolve(const itx_bgzf_block *__restrict
     if (threadIdx.x == 0) status[b] = (uint8_t)rc;
 }
 
+// =====================================================================================================================
+// The decoded stream stays on the device: a WINDOW of inflated bytes per chunk, the BAM records in it located and
+// parsed there (cussamtools/bam.c:179-210 bam_read1 + the fields generic.c:745-905 takes from bam1_core_t, bam.h:169-177),
+// and only the 26-byte-per-record SoA crosses PCIe on the way back.
+//
+// Locating the records is a chain (a record's length says where the next one starts). The window is cut into pieces; a
+// thread per piece GUESSES the first record start in its piece (three well-formed records in a row) and walks on from
+// there; the host then checks the pieces in stream order — a piece counts only if its guess is exactly where the chain
+// of the pieces before it arrives, otherwise it is walked again from there (k_rewalk) — which makes the result exact
+// whatever the guesses were (same scheme as the host reader's locate_records, iteres_amd/host/bamio.c).
+
+#define WIN_HEAD (4u << 20)          /* room before a window's new bytes for the unconsumed tail of the previous one */
+#define PIECE (16u << 10)            /* bytes per located piece */
+#define PIECE_SLOTS (PIECE / 36u + 2u)
+
+struct PieceSum {
+    uint32_t c, end, n, why;         /* guessed start (0xffffffff none), where the walk stopped, starts found; why as the host reader */
+};
+
+static __device__ inline uint32_t ld32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+static __device__ inline uint32_t walk(const uint8_t *u, uint32_t p, uint32_t lim, uint32_t L, uint32_t *off, uint32_t *pn, uint32_t *why)
+{
+    uint32_t n = 0;
+    while (p < lim) {
+        if (p + 4u > L) {
+            *why = 1;
+            *pn = n;
+            return p;
+        }
+        const int32_t bl = (int32_t)ld32(u + p);
+        if (bl < 32) {                                            /* bam.c:186-190: a malformed length ends the file */
+            *why = 2;
+            *pn = n;
+            return p;
+        }
+        if ((uint64_t)p + 4u + (uint32_t)bl > L) {
+            *why = 1;
+            *pn = n;
+            return p;
+        }
+        off[n++] = p;
+        p += 4u + (uint32_t)bl;
+    }
+    *why = 0;
+    *pn = n;
+    return p;
+}
+
+static __device__ inline uint32_t looks_like_record(const uint8_t *u, uint32_t p, uint32_t L, int32_t n_targets)
+{
+    if ((uint64_t)p + 36u > L) return 0;
+    const int32_t bl = (int32_t)ld32(u + p);
+    if (bl < 32 || (uint64_t)p + 4u + (uint32_t)bl > L) return 0;
+    const uint8_t *core = u + p + 4;
+    const int32_t tid = (int32_t)ld32(core), pos = (int32_t)ld32(core + 4), l_qseq = (int32_t)ld32(core + 16), mtid = (int32_t)ld32(core + 20),
+                  mpos = (int32_t)ld32(core + 24);
+    const uint32_t x1 = ld32(core + 8), x2 = ld32(core + 12);
+    const uint32_t l_qname = x1 & 0xffu, n_cigar = x2 & 0xffffu;
+    if (tid < -1 || tid >= n_targets || mtid < -1 || mtid >= n_targets || pos < -1 || mpos < -1 || l_qseq < 0 || l_qname == 0) return 0;
+    const uint64_t need = (uint64_t)l_qname + 4ull * n_cigar + ((uint64_t)l_qseq + 1) / 2 + (uint64_t)l_qseq;
+    if (need > (uint64_t)bl - 32u) return 0;
+    if (u[p + 36u + l_qname - 1u] != 0) return 0;
+    return 4u + (uint32_t)bl;
+}
+
+__global__ __launch_bounds__(64) void k_guess(const uint8_t *__restrict__ u, uint32_t p0, uint32_t L, uint32_t T, int32_t n_targets, PieceSum *__restrict__ sum,
+                                              uint32_t *__restrict__ spec)
+{
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t b = p0 + t * PIECE, lim = L - b > PIECE ? b + PIECE : L;       // T = ceil((L - p0) / PIECE): b < L
+    uint32_t c = 0xffffffffu;
+    if (t == 0) {
+        c = b;
+    } else {
+        for (uint32_t x = b; x < lim; x++) {
+            uint32_t a = x, k = 0;
+            while (k < 3 && a < L) {
+                const uint32_t step = looks_like_record(u, a, L, n_targets);
+                if (!step) break;
+                a += step;
+                k++;
+            }
+            if (k == 3 || (k > 0 && a >= L)) {
+                c = x;
+                break;
+            }
+        }
+    }
+    PieceSum s{c, c, 0, 0};
+    if (c != 0xffffffffu) s.end = walk(u, c, lim, L, spec + (size_t)t * PIECE_SLOTS, &s.n, &s.why);
+    sum[t] = s;
+}
+
+// one piece walked again from where the chain really arrives (one thread: it happens when a guess was misled)
+__global__ void k_rewalk(const uint8_t *__restrict__ u, uint32_t from, uint32_t lim, uint32_t L, uint32_t t, PieceSum *__restrict__ sum, uint32_t *__restrict__ spec)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    PieceSum s{from, from, 0, 0};
+    s.end = walk(u, from, lim, L, spec + (size_t)t * PIECE_SLOTS, &s.n, &s.why);
+    sum[t] = s;
+}
+
+// accepted pieces' starts, in stream order, into one array: base[t] = records before piece t, cnt[t] = its records
+__global__ __launch_bounds__(64) void k_compact(const uint32_t *__restrict__ spec, const uint32_t *__restrict__ base, const uint32_t *__restrict__ cnt, uint32_t T,
+                                                uint32_t *__restrict__ rec_off)
+{
+    const uint32_t t = blockIdx.x;
+    if (t >= T) return;
+    const uint32_t n = cnt[t], b = base[t];
+    for (uint32_t j = threadIdx.x; j < n; j += 64u) rec_off[b + j] = spec[(size_t)t * PIECE_SLOTS + j];
+}
+
+// cussamtools/bam_aux.c:36-48 walk, as the host reader's aux_find: is there an XA tag?
+static __device__ inline bool has_xa(const uint8_t *s, const uint8_t *end)
+{
+    while (s + 3 <= end) {
+        if (s[0] == 'X' && s[1] == 'A') return true;
+        uint32_t type = s[2];
+        if (type >= 'a' && type <= 'z') type -= 32u;
+        s += 3;
+        if (type == 'A' || type == 'C') s += 1;
+        else if (type == 'S') s += 2;
+        else if (type == 'I' || type == 'F') s += 4;
+        else if (type == 'D') s += 8;
+        else if (type == 'Z' || type == 'H') {
+            while (s < end && *s) ++s;
+            ++s;
+        } else if (type == 'B') {
+            if (s + 5 > end) return false;
+            uint32_t sub = s[0];
+            if (sub >= 'a' && sub <= 'z') sub -= 32u;
+            const uint32_t cnt = ld32(s + 1);
+            const uint32_t esz = (sub == 'C' || sub == 'A') ? 1u : (sub == 'S') ? 2u : 4u;
+            if ((uint64_t)cnt * esz > (uint64_t)(end - s)) return false;
+            s += 5u + cnt * esz;
+        } else
+            return false;
+    }
+    return false;
+}
+
+// one thread per record: the fields generic.c:745-905 reads, bam_calend (bam.c:17-27: M, D, N advance) or pos + l_qseq
+__global__ __launch_bounds__(256) void k_parse(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, uint32_t n, int32_t *__restrict__ tid_o,
+                                               int32_t *__restrict__ pos_o, int32_t *__restrict__ end_o, uint8_t *__restrict__ mapq_o, uint8_t *__restrict__ f5_o,
+                                               int32_t *__restrict__ mpos_o, int32_t *__restrict__ isize_o, uint8_t *__restrict__ xa_o, uint32_t *__restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool paired = false, xa = false;
+    if (i < n) {
+        const uint8_t *p = u + rec_off[i];
+        const uint32_t block_len = ld32(p);
+        const uint8_t *core = p + 4, *data = p + 36;
+        const uint32_t dlen = block_len - 32u;
+        const int32_t tid = (int32_t)ld32(core), pos = (int32_t)ld32(core + 4);
+        const uint32_t x1 = ld32(core + 8), x2 = ld32(core + 12);
+        const uint32_t l_qname = x1 & 0xffu, qual = (x1 >> 8) & 0xffu, flag = x2 >> 16, n_cigar = x2 & 0xffffu;
+        const int32_t l_qseq = (int32_t)ld32(core + 16), mpos = (int32_t)ld32(core + 24), isize = (int32_t)ld32(core + 28);
+        int32_t tmpend;
+        if (n_cigar && (uint64_t)l_qname + 4ull * n_cigar <= dlen) {
+            uint32_t e = (uint32_t)pos;
+            const uint8_t *cg = data + l_qname;
+            for (uint32_t k = 0; k < n_cigar; k++) {
+                const uint32_t c = ld32(cg + 4 * k), op = c & 0xfu;
+                if (op == 0 || op == 2 || op == 3) e += c >> 4;
+            }
+            tmpend = (int32_t)e;
+        } else {
+            tmpend = (int32_t)((uint32_t)pos + (uint32_t)l_qseq);             /* generic.c:820 */
+        }
+        tid_o[i] = tid;
+        pos_o[i] = pos;
+        end_o[i] = tmpend;
+        mapq_o[i] = (uint8_t)qual;
+        f5_o[i] = ITX_FLAG5(flag);
+        mpos_o[i] = mpos;
+        isize_o[i] = isize;
+        paired = flag & 1u;
+        const uint64_t ql = l_qseq > 0 ? (uint64_t)l_qseq : 0;
+        const uint64_t off = (uint64_t)l_qname + 4ull * n_cigar + (ql + 1) / 2 + ql;
+        xa = off < dlen && has_xa(data + off, data + dlen);
+        xa_o[i] = xa ? 1 : 0;
+    }
+    const unsigned long long bp = __ballot(paired), bx = __ballot(xa);
+    if ((threadIdx.x & 63u) == 0 && (bp | bx)) atomicOr(flags, (bp ? 1u : 0u) | (bx ? 2u : 0u));
+}
+
 struct itx_inflater {
     int device;
     hipStream_t st[2];
@@ -72,6 +260,21 @@ struct itx_inflater {
     size_t comp_cap, out_cap, status_cap, blk_cap, lit_cap, tok_cap, meta_cap;
     hipEvent_t ev[4];
     float ms_tokens, ms_resolve;
+    // windows of inflated bytes that stay on the device (itx_bamwin_*)
+    struct {
+        uint8_t *buf;
+        size_t cap;
+        uint32_t start, len, consumed;     // unconsumed bytes are buf[start, len); consumed: end of the last parsed record
+    } win[2];
+    itx_bgzf_block *h_blk;                 // a call's block list shifted to the window's offsets
+    size_t h_blk_cap;
+    void *d_sum, *h_sum;                   // PieceSum per piece, and its host copy
+    uint32_t *d_spec, *d_pb, *h_pb, *d_recoff, *d_flags;
+    size_t sum_cap, spec_cap, pb_cap, recoff_cap, soa_cap;
+    int32_t *d_tid, *d_pos, *d_end, *d_mpos, *d_isize;
+    uint8_t *d_mapq, *d_f5, *d_xa;
+    int parsed_w;
+    size_t n_rec;
 };
 
 #define INF_HIP(call)                                                                                     \
@@ -113,6 +316,23 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_lit);
     (void)hipFree(h->d_tok);
     (void)hipFree(h->d_meta);
+    for (int k = 0; k < 2; k++) (void)hipFree(h->win[k].buf);
+    (void)hipFree(h->d_sum);
+    (void)hipFree(h->d_spec);
+    (void)hipFree(h->d_pb);
+    (void)hipFree(h->d_recoff);
+    (void)hipFree(h->d_flags);
+    (void)hipFree(h->d_tid);
+    (void)hipFree(h->d_pos);
+    (void)hipFree(h->d_end);
+    (void)hipFree(h->d_mpos);
+    (void)hipFree(h->d_isize);
+    (void)hipFree(h->d_mapq);
+    (void)hipFree(h->d_f5);
+    (void)hipFree(h->d_xa);
+    if (h->h_sum) (void)hipHostFree(h->h_sum);
+    if (h->h_pb) (void)hipHostFree(h->h_pb);
+    free(h->h_blk);
     for (int k = 0; k < 4; k++)
         if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     free(h);
@@ -204,5 +424,265 @@ extern "C" int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, flo
     if (!h) return ITX_E_ARG;
     if (tokens_ms) *tokens_ms = h->ms_tokens;
     if (resolve_ms) *resolve_ms = h->ms_resolve;
+    return ITX_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------- windows
+
+static int check_blocks(const itx_bgzf_block *blk, size_t n_blk, size_t comp_len, size_t *total)
+{
+    size_t uat = 0;
+    for (size_t i = 0; i < n_blk; i++) {
+        const itx_bgzf_block &b = blk[i];
+        if ((size_t)b.coff + b.csize > comp_len || b.csize < BGZF_HEADER + BGZF_TRAILER || b.uoff != uat || b.usize > 65536u) {
+            itx_set_error("BGZF block %zu does not fit its buffers", i);
+            return ITX_E_ARG;
+        }
+        uat += b.usize;
+    }
+    *total = uat;
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, uint8_t *status, size_t *n_new)
+{
+    if (!h || (w != 0 && w != 1) || !comp || !blk || !status || !n_new) return ITX_E_ARG;
+    *n_new = 0;
+    size_t total = 0;
+    int rc = check_blocks(blk, n_blk, comp_len, &total);
+    if (rc != ITX_OK) return rc;
+    if (comp_len > 0xfffffff0u || total + WIN_HEAD > 0xfffffff0u || n_blk > 0x7fffffffu) return ITX_E_LIMIT;
+    INF_HIP(hipSetDevice(h->device));
+    if ((rc = grow(&h->win[w].buf, &h->win[w].cap, WIN_HEAD + total + 64)) != ITX_OK) return rc;
+    h->win[w].start = h->win[w].consumed = WIN_HEAD;
+    h->win[w].len = WIN_HEAD + (uint32_t)total;
+    if (n_blk == 0) return ITX_OK;
+    if (h->h_blk_cap < n_blk) {
+        free(h->h_blk);
+        h->h_blk_cap = n_blk + n_blk / 4;
+        h->h_blk = (itx_bgzf_block *)malloc(h->h_blk_cap * sizeof *h->h_blk);
+        if (!h->h_blk) return ITX_E_NOMEM;
+    }
+    for (size_t i = 0; i < n_blk; i++) {
+        h->h_blk[i] = blk[i];
+        h->h_blk[i].uoff += WIN_HEAD;
+    }
+    if ((rc = grow(&h->d_comp, &h->comp_cap, comp_len + 64)) != ITX_OK) return rc;
+    if ((rc = grow(&h->d_status, &h->status_cap, n_blk)) != ITX_OK) return rc;
+    if ((rc = grow(&h->d_blk, &h->blk_cap, n_blk)) != ITX_OK) return rc;
+    if ((rc = grow(&h->d_lit, &h->lit_cap, n_blk * (size_t)LIT_STRIDE)) != ITX_OK) return rc;
+    if ((rc = grow(&h->d_tok, &h->tok_cap, n_blk * (size_t)TOK_STRIDE)) != ITX_OK) return rc;
+    if ((rc = grow(&h->d_meta, &h->meta_cap, 3 * n_blk)) != ITX_OK) return rc;
+    hipStream_t st = h->st[0];
+    INF_HIP(hipMemcpyAsync(h->d_blk, h->h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, st));
+    INF_HIP(hipMemcpyAsync(h->d_comp, comp, comp_len, hipMemcpyHostToDevice, st));
+    INF_HIP(hipEventRecord(h->ev[0], st));
+    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)h->d_comp, h->d_blk, (uint32_t)n_blk, h->d_lit, h->d_tok,
+                       h->d_meta);
+    INF_HIP(hipGetLastError());
+    INF_HIP(hipEventRecord(h->ev[1], st));
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, st, h->d_blk, 0u, (uint32_t)n_blk, h->d_lit, h->d_tok, h->d_meta, h->win[w].buf, h->d_status);
+    INF_HIP(hipGetLastError());
+    INF_HIP(hipEventRecord(h->ev[2], st));
+    INF_HIP(hipMemcpyAsync(status, h->d_status, n_blk, hipMemcpyDeviceToHost, st));
+    INF_HIP(hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&h->ms_tokens, h->ev[0], h->ev[1]);
+    (void)hipEventElapsedTime(&h->ms_resolve, h->ev[1], h->ev[2]);
+    *n_new = total;
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_patch(itx_inflater *h, int w, size_t uoff, const void *bytes, size_t len)
+{
+    if (!h || (w != 0 && w != 1) || !bytes || WIN_HEAD + uoff + len > h->win[w].len) return ITX_E_ARG;
+    INF_HIP(hipSetDevice(h->device));
+    INF_HIP(hipMemcpy(h->win[w].buf + WIN_HEAD + uoff, bytes, len, hipMemcpyHostToDevice));
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_truncate(itx_inflater *h, int w, size_t n_new)
+{
+    if (!h || (w != 0 && w != 1) || WIN_HEAD + n_new > h->win[w].len) return ITX_E_ARG;
+    h->win[w].len = WIN_HEAD + (uint32_t)n_new;
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_carry(itx_inflater *h, int from, int to)
+{
+    if (!h || (from != 0 && from != 1) || to != 1 - from) return ITX_E_ARG;
+    const uint32_t tail = h->win[from].len - h->win[from].consumed;
+    if (tail > WIN_HEAD) {
+        itx_set_error("a BAM record of more than %u bytes straddles two chunks: beyond the device decoder (ITX_HOST_INFLATE=1 reads such files)", WIN_HEAD);
+        return ITX_E_LIMIT;
+    }
+    if (h->win[to].start != WIN_HEAD) return ITX_E_STATE;
+    INF_HIP(hipSetDevice(h->device));
+    if (tail) {
+        INF_HIP(hipMemcpyAsync(h->win[to].buf + WIN_HEAD - tail, h->win[from].buf + h->win[from].consumed, tail, hipMemcpyDeviceToDevice, h->st[1]));
+        INF_HIP(hipStreamSynchronize(h->st[1]));
+    }
+    h->win[to].start = h->win[to].consumed = WIN_HEAD - tail;
+    h->win[from].consumed = h->win[from].len;
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_avail(const itx_inflater *h, int w, size_t *bytes)
+{
+    if (!h || (w != 0 && w != 1) || !bytes) return ITX_E_ARG;
+    *bytes = h->win[w].len - h->win[w].consumed;
+    return ITX_OK;
+}
+
+/* bytes [off, off + len) of the window's unconsumed part, to the host */
+extern "C" int itx_bamwin_peek(itx_inflater *h, int w, size_t off, void *dst, size_t len)
+{
+    if (!h || (w != 0 && w != 1) || !dst || (size_t)h->win[w].consumed + off + len > h->win[w].len) return ITX_E_ARG;
+    INF_HIP(hipSetDevice(h->device));
+    if (len) INF_HIP(hipMemcpy(dst, h->win[w].buf + h->win[w].consumed + off, len, hipMemcpyDeviceToHost));
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_skip(itx_inflater *h, int w, size_t n)
+{
+    if (!h || (w != 0 && w != 1) || (size_t)h->win[w].consumed + n > h->win[w].len) return ITX_E_ARG;
+    h->win[w].consumed += (uint32_t)n;
+    h->win[w].start = h->win[w].consumed;
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_parse(itx_inflater *h, int w, int n_targets, size_t *n_rec, int *malformed, int *flags, size_t *rewalked)
+{
+    if (!h || (w != 0 && w != 1) || !n_rec || !malformed || !flags) return ITX_E_ARG;
+    *n_rec = 0;
+    *malformed = 0;
+    *flags = 0;
+    h->n_rec = 0;
+    h->parsed_w = w;
+    const uint32_t p0 = h->win[w].consumed, L = h->win[w].len;
+    if (p0 >= L) return ITX_OK;
+    INF_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->st[1];
+    const uint32_t T = (L - p0 + PIECE - 1) / PIECE;
+    int rc;
+    {
+        size_t cap = h->sum_cap;
+        if ((rc = grow((PieceSum **)&h->d_sum, &cap, (size_t)T)) != ITX_OK) return rc;
+        if (cap != h->sum_cap) {
+            if (h->h_sum) (void)hipHostFree(h->h_sum);
+            h->h_sum = nullptr;
+            INF_HIP(hipHostMalloc(&h->h_sum, cap * sizeof(PieceSum), hipHostMallocDefault));
+            h->sum_cap = cap;
+        }
+        cap = h->pb_cap;
+        if ((rc = grow(&h->d_pb, &cap, 2 * (size_t)T)) != ITX_OK) return rc;
+        if (cap != h->pb_cap) {
+            if (h->h_pb) (void)hipHostFree(h->h_pb);
+            h->h_pb = nullptr;
+            INF_HIP(hipHostMalloc((void **)&h->h_pb, cap * sizeof(uint32_t), hipHostMallocDefault));
+            h->pb_cap = cap;
+        }
+    }
+    if ((rc = grow(&h->d_spec, &h->spec_cap, (size_t)T * PIECE_SLOTS)) != ITX_OK) return rc;
+    if (!h->d_flags) INF_HIP(hipMalloc((void **)&h->d_flags, 16));
+    PieceSum *d_sum = (PieceSum *)h->d_sum, *sum = (PieceSum *)h->h_sum;
+    const uint8_t *u = h->win[w].buf;
+    hipLaunchKernelGGL(k_guess, dim3((T + 63) / 64), dim3(64), 0, st, u, p0, L, T, (int32_t)n_targets, d_sum, h->d_spec);
+    INF_HIP(hipGetLastError());
+    INF_HIP(hipMemcpyAsync(sum, d_sum, (size_t)T * sizeof(PieceSum), hipMemcpyDeviceToHost, st));
+    INF_HIP(hipStreamSynchronize(st));
+    // in stream order: a piece counts if its guess is where the chain arrives, else it is walked again from there
+    uint32_t cur = p0, endp = p0, why = 0, tot = 0;
+    uint32_t *base = h->h_pb, *cnt = h->h_pb + T;
+    size_t redo = 0;
+    for (uint32_t t = 0; t < T; t++) {
+        const uint32_t b = p0 + t * PIECE, lim = L - b > PIECE ? b + PIECE : L;
+        base[t] = tot;
+        cnt[t] = 0;
+        if (why || cur >= lim) continue;                        // the stream ended, or a record reaches over the whole piece
+        if (sum[t].c != cur) {
+            hipLaunchKernelGGL(k_rewalk, dim3(1), dim3(1), 0, st, u, cur, lim, L, t, d_sum, h->d_spec);
+            INF_HIP(hipGetLastError());
+            INF_HIP(hipMemcpyAsync(&sum[t], d_sum + t, sizeof(PieceSum), hipMemcpyDeviceToHost, st));
+            INF_HIP(hipStreamSynchronize(st));
+            redo++;
+        }
+        cnt[t] = sum[t].n;
+        tot += sum[t].n;
+        endp = cur = sum[t].end;
+        why = sum[t].why;
+    }
+    if (rewalked) *rewalked = redo;
+    if (why == 2) {                                               // bam.c:186-190: a malformed length ends the file
+        *malformed = 1;
+        h->win[w].len = endp;
+    }
+    h->win[w].consumed = tot ? endp : p0;
+    if (why == 2 && tot == 0) h->win[w].consumed = endp;
+    if (tot == 0) return ITX_OK;
+    if ((rc = grow(&h->d_recoff, &h->recoff_cap, (size_t)tot)) != ITX_OK) return rc;
+    if (h->soa_cap < tot) {
+        const size_t want = (size_t)tot + tot / 4;
+        int32_t **i32s[5] = {&h->d_tid, &h->d_pos, &h->d_end, &h->d_mpos, &h->d_isize};
+        uint8_t **u8s[3] = {&h->d_mapq, &h->d_f5, &h->d_xa};
+        for (auto pp : i32s) {
+            if (*pp) INF_HIP(hipFree(*pp));
+            *pp = nullptr;
+            INF_HIP(hipMalloc((void **)pp, want * 4));
+        }
+        for (auto pp : u8s) {
+            if (*pp) INF_HIP(hipFree(*pp));
+            *pp = nullptr;
+            INF_HIP(hipMalloc((void **)pp, want));
+        }
+        h->soa_cap = want;
+    }
+    INF_HIP(hipMemcpyAsync(h->d_pb, h->h_pb, 2 * (size_t)T * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    INF_HIP(hipMemsetAsync(h->d_flags, 0, 4, st));
+    hipLaunchKernelGGL(k_compact, dim3(T), dim3(64), 0, st, h->d_spec, h->d_pb, h->d_pb + T, T, h->d_recoff);
+    INF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_parse, dim3((tot + 255) / 256), dim3(256), 0, st, u, h->d_recoff, tot, h->d_tid, h->d_pos, h->d_end, h->d_mapq, h->d_f5, h->d_mpos, h->d_isize,
+                       h->d_xa, h->d_flags);
+    INF_HIP(hipGetLastError());
+    uint32_t fl = 0;
+    INF_HIP(hipMemcpyAsync(&fl, h->d_flags, 4, hipMemcpyDeviceToHost, st));
+    INF_HIP(hipStreamSynchronize(st));
+    *flags = (int)fl;
+    *n_rec = tot;
+    h->n_rec = tot;
+    return ITX_OK;
+}
+
+/* records [first, first + n) of the last parse: SoA into host arrays (any may be NULL), their offsets in the window and
+ * XA marks on request */
+extern "C" int itx_bamwin_fetch(itx_inflater *h, size_t first, size_t n, const itx_staging *dst, size_t dst_at, uint32_t *rec_off, uint8_t *xa)
+{
+    if (!h || first + n > h->n_rec) return ITX_E_ARG;
+    if (n == 0) return ITX_OK;
+    INF_HIP(hipSetDevice(h->device));
+    hipStream_t st = h->st[1];
+    if (dst) {
+        if (dst_at + n > dst->capacity) return ITX_E_ARG;
+        if (dst->tid) INF_HIP(hipMemcpyAsync(dst->tid + dst_at, h->d_tid + first, n * 4, hipMemcpyDeviceToHost, st));
+        if (dst->pos) INF_HIP(hipMemcpyAsync(dst->pos + dst_at, h->d_pos + first, n * 4, hipMemcpyDeviceToHost, st));
+        if (dst->tmpend) INF_HIP(hipMemcpyAsync(dst->tmpend + dst_at, h->d_end + first, n * 4, hipMemcpyDeviceToHost, st));
+        if (dst->mapq) INF_HIP(hipMemcpyAsync(dst->mapq + dst_at, h->d_mapq + first, n, hipMemcpyDeviceToHost, st));
+        if (dst->flag5) INF_HIP(hipMemcpyAsync(dst->flag5 + dst_at, h->d_f5 + first, n, hipMemcpyDeviceToHost, st));
+        if (dst->mpos) INF_HIP(hipMemcpyAsync(dst->mpos + dst_at, h->d_mpos + first, n * 4, hipMemcpyDeviceToHost, st));
+        if (dst->isize) INF_HIP(hipMemcpyAsync(dst->isize + dst_at, h->d_isize + first, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (rec_off) INF_HIP(hipMemcpyAsync(rec_off, h->d_recoff + first, n * 4, hipMemcpyDeviceToHost, st));
+    if (xa) INF_HIP(hipMemcpyAsync(xa, h->d_xa + first, n, hipMemcpyDeviceToHost, st));
+    INF_HIP(hipStreamSynchronize(st));
+    return ITX_OK;
+}
+
+/* raw bytes [off, off + len) of the parsed window (offsets as itx_bamwin_fetch's rec_off), to the host */
+extern "C" int itx_bamwin_bytes(itx_inflater *h, size_t off, void *dst, size_t len)
+{
+    if (!h || !dst) return ITX_E_ARG;
+    const int w = h->parsed_w;
+    if (off + len > h->win[w].cap) return ITX_E_ARG;
+    INF_HIP(hipSetDevice(h->device));
+    if (len) INF_HIP(hipMemcpy(dst, h->win[w].buf + off, len, hipMemcpyDeviceToHost));
     return ITX_OK;
 }

@@ -24,6 +24,8 @@ EXPORTS = [
     "itx_engine_classify_device", "itx_engine_first_hit_slot", "itx_engine_first_hit_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
     "itx_engine_partial_size", "itx_engine_export_partial", "itx_engine_finish_partial",
     "itx_inflater_create", "itx_inflater_destroy", "itx_inflate_bgzf", "itx_inflater_last_ms", "itx_pinned_alloc", "itx_pinned_free",
+    "itx_bamwin_push", "itx_bamwin_patch", "itx_bamwin_truncate", "itx_bamwin_carry", "itx_bamwin_avail", "itx_bamwin_peek", "itx_bamwin_skip",
+    "itx_bamwin_parse", "itx_bamwin_fetch", "itx_bamwin_bytes",
 ]
 
 
@@ -111,6 +113,16 @@ def load():
     L.itx_inflater_destroy.restype = None
     L.itx_inflate_bgzf.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.itx_inflater_last_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.itx_bamwin_push.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.itx_bamwin_patch.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.itx_bamwin_truncate.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.itx_bamwin_carry.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.itx_bamwin_avail.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+    L.itx_bamwin_peek.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.itx_bamwin_skip.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    L.itx_bamwin_parse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.itx_bamwin_fetch.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(Staging), C.c_size_t, C.c_void_p, C.c_void_p]
+    L.itx_bamwin_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.itx_pinned_alloc.argtypes = [C.c_size_t]
     L.itx_pinned_alloc.restype = C.c_void_p
     L.itx_pinned_free.argtypes = [C.c_void_p]

@@ -59,9 +59,17 @@ struct aln_reader {
     int eof;                  /* no more compressed input (end of file or a damaged block)                     */
     struct blk *blk;          /* block index of the chunk being inflated                                        */
     size_t blk_cap;
-    itx_bgzf_block *dblk;     /* the same for the device inflater, and its per-block verdicts                   */
+    /* device decoder (aln_use_device): two windows of inflated bytes live on the device, dw is the one being consumed */
+    int dev, dw, dparsed, dlast, dflags;
+    size_t dn_rec, drec_next, d_rewalked;
+    itx_bgzf_block *dblk;     /* block index of a chunk for the device, and its per-block verdicts                */
     uint8_t *dstatus;
     size_t dblk_cap;
+    uint8_t *hdr;             /* host copy of the window's front while the header is parsed                       */
+    size_t hdr_len, hdr_pos;
+    uint32_t *d_off;          /* side channels: offsets, XA marks and raw bytes of a batch's records              */
+    uint8_t *d_xa, *d_raw;
+    size_t d_side_cap, d_raw_cap;
     /* read-ahead (bgzf_load_chunk): spare buffer the loader thread inflates the next chunk into */
     uint8_t *nbuf;
     size_t ncap, nlen;
@@ -77,18 +85,22 @@ struct aln_reader {
 };
 
 /* ---- BGZF ------------------------------------------------------------------------------------------------ */
-static aln_device_inflate dev_inflate;       /* .inflate == NULL: the host's threads inflate */
-void aln_use_device_inflate(const aln_device_inflate *ops)
+static aln_device_ops dev;                   /* .push == NULL: the host decodes */
+void aln_use_device(const aln_device_ops *ops)
 {
-    if (ops) dev_inflate = *ops;
-    else memset(&dev_inflate, 0, sizeof dev_inflate);
+    if (ops) dev = *ops;
+    else memset(&dev, 0, sizeof dev);
 }
+#define DEV_CHK(call, what)                                                                                    \
+    do {                                                                                                       \
+        if ((call) != 0) die("device decoder: %s failed: %s", what, dev.last_error ? dev.last_error() : "?"); \
+    } while (0)
 
 /* the big byte buffers (compressed chunks, inflated chunks): page-locked when the device inflates */
 static uint8_t *buf_alloc(size_t n)
 {
-    if (dev_inflate.alloc) {
-        uint8_t *p = dev_inflate.alloc(n);
+    if (dev.alloc) {
+        uint8_t *p = dev.alloc(n);
         if (!p) die("cannot get %zu bytes of page-locked memory", n);
         return p;
     }
@@ -97,7 +109,7 @@ static uint8_t *buf_alloc(size_t n)
 static void buf_free(uint8_t *p)
 {
     if (!p) return;
-    if (dev_inflate.release) dev_inflate.release(p);
+    if (dev.release) dev.release(p);
     else free(p);
 }
 static uint8_t *buf_grow(uint8_t *old, size_t keep, size_t ncap)
@@ -116,7 +128,7 @@ static size_t chunk_compressed(void)
     if (!v) {
         const char *e = getenv("ITX_BGZF_CHUNK");
         const long x = e ? atol(e) : 0;
-        v = x >= 1 ? (size_t)x : dev_inflate.inflate ? CHUNK_COMPRESSED_DEVICE : CHUNK_COMPRESSED_DEFAULT;
+        v = x >= 1 ? (size_t)x : dev.push ? CHUNK_COMPRESSED_DEVICE : CHUNK_COMPRESSED_DEFAULT;
     }
     return v;
 }
@@ -229,16 +241,10 @@ static size_t raw_next(aln_reader *r)
     return got;
 }
 
-static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, size_t at, int *peof)
+/* The complete BGZF blocks of the raw bytes at hand (bgzf.c:401-411 header check, BSIZE, the ISIZE trailer) into r->blk;
+ * *poff = compressed bytes they take, *putot = bytes they inflate to. */
+static size_t index_blocks(aln_reader *r, size_t *poff, size_t *putot, int *pdamaged)
 {
-    double tq = now_s();
-    const size_t got = raw_next(r);
-    t_io += now_s() - tq;
-    if (r->clen == 0) {
-        *peof = 1;
-        return 0;
-    }
-    /* index the complete blocks */
     struct blk *bl = r->blk;
     size_t nb = 0, off = 0, utot = 0;
     int damaged = 0;
@@ -271,6 +277,25 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
         utot += usize;
         off += bsize;
     }
+    *poff = off;
+    *putot = utot;
+    *pdamaged = damaged;
+    return nb;
+}
+
+static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, size_t at, int *peof)
+{
+    double tq = now_s();
+    const size_t got = raw_next(r);
+    t_io += now_s() - tq;
+    if (r->clen == 0) {
+        *peof = 1;
+        return 0;
+    }
+    size_t off = 0, utot = 0;
+    int damaged = 0;
+    const size_t nb = index_blocks(r, &off, &utot, &damaged);
+    struct blk *bl = r->blk;
     if (at + utot + 64 > *pcap) {
         const size_t old_cap = *pcap;
         *pcap = (at + utot) * 5 / 4 + BGZF_MAX + 64;
@@ -281,31 +306,9 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
     uint8_t *dst0 = *pbuf + at;
     const struct blk *blocks = bl;
     const uint8_t *cbase = r->cbuf;
-    if (dev_inflate.inflate && nb) {
-        /* the device takes the whole chunk: one wavefront lane per block for the Huffman half, one wave per block for the
-         * copies (csrc/itx_inflate.hip). A block it flags is looked at again by zlib below, whose verdict is the reference's. */
-        if (r->dblk_cap < nb) {
-            r->dblk_cap = nb + nb / 4;
-            r->dblk = xrealloc(r->dblk, sizeof *r->dblk * r->dblk_cap);
-            r->dstatus = xrealloc(r->dstatus, r->dblk_cap);
-        }
-        for (size_t i = 0; i < nb; i++) {
-            r->dblk[i].coff = (uint32_t)bl[i].coff;
-            r->dblk[i].csize = (uint32_t)bl[i].csize;
-            r->dblk[i].uoff = (uint32_t)bl[i].uoff;
-            r->dblk[i].usize = (uint32_t)bl[i].usize;
-        }
-        if (dev_inflate.inflate(dev_inflate.ctx, cbase, off, r->dblk, nb, dst0, utot, r->dstatus) != 0) die("the device inflater failed (HIP error)");
-        for (size_t i = 0; i < nb; i++)
-            if (r->dstatus[i] && blocks[i].usize) {
-                if (inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
-                else fprintf(stderr, "[iteres] note: BGZF block at chunk offset %zu declined by the device decoder (code %d), inflated by zlib\n", blocks[i].coff, r->dstatus[i]);
-            }
-    } else {
 #pragma omp parallel for schedule(dynamic, 16) reduction(| : bad)
-        for (long i = 0; i < (long)nb; i++)
-            if (blocks[i].usize && inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
-    }
+    for (long i = 0; i < (long)nb; i++)
+        if (blocks[i].usize && inflate_block(cbase + blocks[i].coff, blocks[i].csize, dst0 + blocks[i].uoff, blocks[i].usize) != 0) bad |= 1;
     t_inflate += now_s() - tq;
     if (bad) {
         /* a block that does not inflate ends the stream there, like bgzf_read returning an error (bgzf.c:471-521) */
@@ -324,6 +327,115 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
     return utot;
 }
 
+
+static void pf_request(aln_reader *r);
+
+/* ---- the device decoder (aln_use_device): this side only moves compressed bytes in ------------------------------------
+ * Window w of the device receives the inflated blocks of the next raw chunk. A block the device decoder flags is given
+ * to zlib here, whose verdict is the reference's: inflated after all, its bytes are patched in; not inflatable, the
+ * stream ends in front of it (bgzf.c:471-521). Returns the inflated bytes added. */
+static size_t dev_fill(aln_reader *r, int w, int *peof)
+{
+    double tq = now_s();
+    const size_t got = raw_next(r);
+    t_io += now_s() - tq;
+    size_t off = 0, utot = 0, n_new = 0;
+    int damaged = 0;
+    const size_t nb = r->clen ? index_blocks(r, &off, &utot, &damaged) : 0;
+    if (r->dblk_cap < nb + 1) {
+        r->dblk_cap = nb + nb / 4 + 1;
+        r->dblk = xrealloc(r->dblk, sizeof *r->dblk * r->dblk_cap);
+        r->dstatus = xrealloc(r->dstatus, r->dblk_cap);
+    }
+    const struct blk *bl = r->blk;
+    for (size_t i = 0; i < nb; i++) {
+        r->dblk[i].coff = (uint32_t)bl[i].coff;
+        r->dblk[i].csize = (uint32_t)bl[i].csize;
+        r->dblk[i].uoff = (uint32_t)bl[i].uoff;
+        r->dblk[i].usize = (uint32_t)bl[i].usize;
+    }
+    tq = now_s();
+    static const uint8_t none[16];
+    DEV_CHK(dev.push(dev.ctx, w, r->clen ? r->cbuf : none, off, r->dblk, nb, r->dstatus, &n_new), "push");
+    for (size_t i = 0; i < nb; i++)
+        if (r->dstatus[i]) {
+            uint8_t tmp[BGZF_MAX + 8];
+            if (inflate_block(r->cbuf + bl[i].coff, bl[i].csize, tmp, bl[i].usize) == 0) {
+                fprintf(stderr, "[iteres] note: BGZF block at chunk offset %zu declined by the device decoder (code %d), inflated by zlib\n", bl[i].coff, r->dstatus[i]);
+                DEV_CHK(dev.patch(dev.ctx, w, bl[i].uoff, tmp, bl[i].usize), "patch");
+            } else {
+                DEV_CHK(dev.truncate(dev.ctx, w, bl[i].uoff), "truncate");
+                n_new = bl[i].uoff;
+                damaged = 1;
+                break;
+            }
+        }
+    t_inflate += now_s() - tq;
+    r->cbuf += off;
+    r->clen -= off;
+    if (damaged || (got == 0 && nb == 0)) *peof = 1;
+    return n_new;
+}
+
+/* The next window becomes the current one: the unconsumed tail (a partial record, or header bytes) moves in front of its
+ * fresh bytes. Synchronous while the header is read, from the read-ahead thread afterwards. Returns bytes added. */
+static size_t dev_advance(aln_reader *r)
+{
+    if (r->eof) return 0;
+    size_t n;
+    int eof = 0;
+    const int nxt = 1 - r->dw;
+    if (!r->pf_on) {
+        n = dev_fill(r, nxt, &eof);
+    } else {
+        pthread_mutex_lock(&r->pf_mu);
+        while (r->pf_state != 2) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
+        r->pf_state = 0;
+        pthread_mutex_unlock(&r->pf_mu);
+        n = r->nlen;
+        eof = r->n_eof;
+    }
+    DEV_CHK(dev.carry(dev.ctx, r->dw, nxt), "carry");
+    r->dw = nxt;
+    r->dparsed = 0;
+    r->dn_rec = r->drec_next = 0;
+    if (eof) r->eof = 1;
+    else if (r->pf_on) pf_request(r);
+    return n;
+}
+
+/* sequential read of n bytes from the device window's front (header parsing): through a host copy fetched 1 MiB at a time */
+static size_t dev_read(aln_reader *r, void *dst, size_t n)
+{
+    for (;;) {
+        if (r->hdr_len - r->hdr_pos >= n) {
+            memcpy(dst, r->hdr + r->hdr_pos, n);
+            r->hdr_pos += n;
+            return n;
+        }
+        size_t avail = 0;
+        DEV_CHK(dev.avail(dev.ctx, r->dw, &avail), "avail");
+        if (avail > r->hdr_len) {                                  /* more of this window */
+            size_t want = r->hdr_pos + n > r->hdr_len + (1u << 20) ? r->hdr_pos + n : r->hdr_len + (1u << 20);
+            if (want > avail) want = avail;
+            r->hdr = xrealloc(r->hdr, want);
+            DEV_CHK(dev.peek(dev.ctx, r->dw, r->hdr_len, r->hdr + r->hdr_len, want - r->hdr_len), "peek");
+            r->hdr_len = want;
+            continue;
+        }
+        /* the window is used up: what was read is consumed, the rest travels to the next window */
+        if (r->eof) {
+            const size_t k = r->hdr_len - r->hdr_pos;
+            memcpy(dst, r->hdr + r->hdr_pos, k);
+            r->hdr_pos += k;
+            return k;
+        }
+        DEV_CHK(dev.skip(dev.ctx, r->dw, r->hdr_pos), "skip");
+        r->hdr_len = r->hdr_pos = 0;
+        dev_advance(r);
+    }
+}
+
 /* ---- read-ahead: while the caller hops over and parses one chunk, a loader thread reads and inflates the next one
  * into the spare buffer, behind PF_HEAD bytes of room for the caller's unconsumed tail (a partial record). */
 #define PF_HEAD (4u << 20)
@@ -336,7 +448,7 @@ static void *pf_main(void *arg)
         if (r->pf_stop) break;
         pthread_mutex_unlock(&r->pf_mu);
         int eof = 0;
-        const size_t n = bgzf_inflate_chunk(r, &r->nbuf, &r->ncap, PF_HEAD, &eof);
+        const size_t n = r->dev ? dev_fill(r, 1 - r->dw, &eof) : bgzf_inflate_chunk(r, &r->nbuf, &r->ncap, PF_HEAD, &eof);
         pthread_mutex_lock(&r->pf_mu);
         r->nlen = n;
         r->n_eof = eof;
@@ -419,6 +531,7 @@ static size_t bgzf_load_chunk(aln_reader *r)
 /* sequential read of n bytes (header parsing) */
 static size_t bgzf_read(aln_reader *r, void *dst, size_t n)
 {
+    if (r->dev) return dev_read(r, dst, n);
     while (r->ulen - r->upos < n) {
         if (bgzf_load_chunk(r) == 0 && r->eof) break;
     }
@@ -522,7 +635,14 @@ aln_reader *aln_open(const char *path, int is_sam)
     if (is_sam) {
         rc = sam_read_header(r);
     } else {
+        r->dev = dev.push != NULL;
         rc = bam_read_header(r);
+        if (r->dev && rc == 0) {
+            DEV_CHK(dev.skip(dev.ctx, r->dw, r->hdr_pos), "skip");                 /* the records start here */
+            free(r->hdr);
+            r->hdr = NULL;
+            r->hdr_len = r->hdr_pos = 0;
+        }
     }
     if (rc != 0) {
         aln_close(r);
@@ -537,7 +657,7 @@ void aln_close(aln_reader *r)
     if (!r) return;
     if (getenv("ITX_TIMING") && !r->is_sam)
         fprintf(stderr, "[itx timing] BAM decode so far: file read %.3f s, inflate (%s) %.3f s, record hop %.3f s (%zu pieces, %zu walked again), parse %.3f s\n", t_io,
-                ld_state == 1 ? "libdeflate" : "zlib", t_inflate, t_hop, r->hop_pieces, r->hop_redone, t_parse);
+                r->dev ? "device" : ld_state == 1 ? "libdeflate" : "zlib", t_inflate, t_hop, r->hop_pieces, r->hop_redone + r->d_rewalked, t_parse);
     if (r->pf_on) {
         pthread_mutex_lock(&r->pf_mu);
         while (r->pf_state == 1) pthread_cond_wait(&r->pf_cv, &r->pf_mu);      /* let a chunk in flight land */
@@ -561,6 +681,10 @@ void aln_close(aln_reader *r)
     free(r->blk);
     free(r->dblk);
     free(r->dstatus);
+    free(r->hdr);
+    free(r->d_off);
+    free(r->d_xa);
+    free(r->d_raw);
     for (int i = 0; i < r->n_targets; i++) free(r->tname[i]);
     free(r->tname);
     names_free(&r->tnames);
@@ -832,8 +956,98 @@ static void locate_records(aln_reader *r)
     if (r->n_rec) r->upos = p;                                     /* consumed up to here once these are parsed */
 }
 
+/* The device decoder's batch: the records of the current window are located and parsed on the device in one go; a batch
+ * is a slice of them copied into the staging arrays. Read names and XA / NM strings, when somebody wants them, are cut
+ * out of the records' raw bytes, fetched for just the records concerned. */
+static size_t dev_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
+{
+    size_t n = 0;
+    if (!r->pf_on && !r->eof) pf_start(r);
+    while (n < cap) {
+        if (r->drec_next == r->dn_rec) {
+            if (!r->dparsed) {
+                const double th = now_s();
+                int malformed = 0, flags = 0;
+                size_t redo = 0;
+                DEV_CHK(dev.parse(dev.ctx, r->dw, r->n_targets, &r->dn_rec, &malformed, &flags, &redo), "parse");
+                t_hop += now_s() - th;
+                r->dparsed = 1;
+                r->drec_next = 0;
+                r->d_rewalked += redo;
+                r->dflags = flags;
+                if (malformed) r->dlast = 1;                       /* bam.c:186-190: nothing after this window counts */
+                continue;
+            }
+            if (r->dlast || r->eof) break;                         /* end of input (a truncated tail record is dropped) */
+            dev_advance(r);
+            continue;
+        }
+        size_t m = r->dn_rec - r->drec_next;
+        if (m > cap - n) m = cap - n;
+        const double tp = now_s();
+        const int want_q = side && side->want_qnames, want_a = side && side->want_aux && (r->dflags & 2);
+        if (want_q || want_a) {
+            if (r->d_side_cap < m + 1) {
+                r->d_side_cap = m + m / 4 + 1;
+                r->d_off = xrealloc(r->d_off, sizeof(uint32_t) * r->d_side_cap);
+                r->d_xa = xrealloc(r->d_xa, r->d_side_cap);
+            }
+            DEV_CHK(dev.fetch(dev.ctx, r->drec_next, m, st, n, r->d_off, r->d_xa), "fetch");
+            /* the raw bytes from the first wanted record to the end of the last one */
+            size_t i0 = 0, i1 = m;
+            if (!want_q) {
+                while (i0 < m && !r->d_xa[i0]) i0++;
+                while (i1 > i0 && !r->d_xa[i1 - 1]) i1--;
+            }
+            if (i1 > i0) {
+                uint8_t lenb[4];
+                DEV_CHK(dev.bytes(dev.ctx, r->d_off[i1 - 1], lenb, 4), "bytes");
+                const size_t lo = r->d_off[i0], hi = (size_t)r->d_off[i1 - 1] + 4 + (size_t)rd_u32(lenb);
+                if (r->d_raw_cap < hi - lo) {
+                    r->d_raw_cap = (hi - lo) + (hi - lo) / 4;
+                    free(r->d_raw);
+                    r->d_raw = xmalloc(r->d_raw_cap);
+                }
+                DEV_CHK(dev.bytes(dev.ctx, lo, r->d_raw, hi - lo), "bytes");
+                const uint8_t *raw = r->d_raw;
+                const uint32_t *ro = r->d_off;
+                const uint8_t *xa = r->d_xa;
+#pragma omp parallel for schedule(static)
+                for (long i = (long)i0; i < (long)i1; i++)
+                    if (want_q || xa[i]) {
+                        int a1 = 0, x1 = 0;
+                        bam_parse_one(raw + (ro[i] - lo), n + (size_t)i, st, side, &a1, &x1);   /* the same field values again, plus the strings */
+                    } else {
+                        side->xa[n + (size_t)i] = NULL;
+                        side->nm[n + (size_t)i] = 0;
+                    }
+            }
+            if (side->want_aux)
+                for (size_t i = 0; i < m; i++)
+                    if (i < i0 || i >= i1) {
+                        side->xa[n + i] = NULL;
+                        side->nm[n + i] = 0;
+                    }
+        } else {
+            DEV_CHK(dev.fetch(dev.ctx, r->drec_next, m, st, n, NULL, NULL), "fetch");
+            if (side && side->want_aux)
+                for (size_t i = 0; i < m; i++) {
+                    side->xa[n + i] = NULL;
+                    side->nm[n + i] = 0;
+                }
+        }
+        t_parse += now_s() - tp;
+        if (r->dflags & 1) *any_paired = 1;
+        if (r->dflags & 2) *aux_xa = 1;
+        r->drec_next += m;
+        n += m;
+    }
+    return n;
+}
+
 static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
+    if (r->dev) return dev_read_batch(r, st, cap, side, any_paired, aux_xa);
     size_t n = 0;
     if (!r->pf_on && !r->eof) pf_start(r);
     while (n < cap) {

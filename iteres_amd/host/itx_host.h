@@ -68,16 +68,27 @@ void rmsk_free(rmsk_t *r);
 
 /* ---- alignment input: BAM (BGZF) or SAM text, decoded into the engine's record SoA */
 typedef struct aln_reader aln_reader;
-/* BGZF blocks inflated on the device (include/iteres_amd.h: itx_inflate_bgzf) instead of by the host's threads. The
- * reader stays free of any link-time dependency on the HIP library: the driver hands it these entry points before it
- * opens a file. `alloc` / `release`: page-locked memory for the buffers that cross PCIe. NULL restores host inflate. */
-typedef struct aln_device_inflate {
-    void *ctx;
-    int (*inflate)(void *ctx, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, void *out, size_t out_len, uint8_t *status);
+/* BAM decoding on the device (include/iteres_amd.h: itx_bamwin_*): BGZF blocks inflated, records located and parsed there;
+ * the reader only moves compressed bytes in and the per-record arrays out. The reader stays free of any link-time
+ * dependency on the HIP library: the driver hands it the entry points before it opens a file. `alloc` / `release`:
+ * page-locked memory for the compressed chunks. NULL restores the host decoder. */
+typedef struct aln_device_ops {
+    itx_inflater *ctx;
+    int (*push)(itx_inflater *, int, const void *, size_t, const itx_bgzf_block *, size_t, uint8_t *, size_t *);
+    int (*patch)(itx_inflater *, int, size_t, const void *, size_t);
+    int (*truncate)(itx_inflater *, int, size_t);
+    int (*carry)(itx_inflater *, int, int);
+    int (*avail)(const itx_inflater *, int, size_t *);
+    int (*peek)(itx_inflater *, int, size_t, void *, size_t);
+    int (*skip)(itx_inflater *, int, size_t);
+    int (*parse)(itx_inflater *, int, int, size_t *, int *, int *, size_t *);
+    int (*fetch)(itx_inflater *, size_t, size_t, const itx_staging *, size_t, uint32_t *, uint8_t *);
+    int (*bytes)(itx_inflater *, size_t, void *, size_t);
     void *(*alloc)(size_t bytes);
     void (*release)(void *p);
-} aln_device_inflate;
-void aln_use_device_inflate(const aln_device_inflate *ops);
+    const char *(*last_error)(void);
+} aln_device_ops;
+void aln_use_device(const aln_device_ops *ops);
 aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the file cannot be opened / has no header */
 void aln_close(aln_reader *r);
 int aln_n_targets(const aln_reader *r);

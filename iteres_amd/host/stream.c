@@ -27,11 +27,12 @@ static double now_s(void)
 static pthread_t warm_thread;
 static int warm_on, warm_bam;
 
-/* BGZF blocks are inflated on the device (include/iteres_amd.h: itx_inflate_bgzf) unless ITX_HOST_INFLATE is set. The
- * reader's big buffers then have to be page-locked, and locking a gigabyte takes a good fraction of a second: the helper
- * thread gets them ready while the main thread parses the rmsk file, and hands them out from this little pool. */
+/* BAM input is decoded on the device (include/iteres_amd.h: itx_bamwin_*: blocks inflated, records located and parsed
+ * there) unless ITX_HOST_INFLATE is set. The reader's compressed-chunk buffers then have to be page-locked, which takes
+ * its time: the helper thread gets them ready while the main thread parses the rmsk file, and hands them out from this
+ * little pool. */
 static itx_inflater *g_inflater;
-#define POOL_N 4
+#define POOL_N 2
 static struct { void *p; size_t cap; int used; } pool[POOL_N];
 static pthread_mutex_t pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static void *pool_alloc(size_t n)
@@ -56,10 +57,6 @@ static void pool_release(void *p)
     pthread_mutex_unlock(&pool_mu);
     itx_pinned_free(p);
 }
-static int dev_inflate_call(void *ctx, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, void *out, size_t out_len, uint8_t *status)
-{
-    return itx_inflate_bgzf((itx_inflater *)ctx, comp, comp_len, blk, n_blk, out, out_len, status);
-}
 
 static void *warm_main(void *arg)
 {
@@ -68,9 +65,8 @@ static void *warm_main(void *arg)
     const int ndev = itx_device_count();
     const double b = now_s();
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(0, &g_inflater) == ITX_OK) {
-        /* two compressed chunks and two inflated ones (a BAM inflates about four- to fivefold; the reader grows what
-         * turns out too small) */
-        static const size_t want[POOL_N] = {(128u << 20) + (1u << 17), (128u << 20) + (1u << 17), 800u << 20, 800u << 20};
+        /* the two compressed chunks the reader alternates between */
+        static const size_t want[POOL_N] = {(128u << 20) + (1u << 17), (128u << 20) + (1u << 17)};
         for (int i = 0; i < POOL_N; i++) {
             pool[i].p = itx_pinned_alloc(want[i]);
             pool[i].cap = pool[i].p ? want[i] : 0;
@@ -166,8 +162,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     int ndev = itx_device_count();
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
     if (g_inflater) {
-        const aln_device_inflate ops = {g_inflater, dev_inflate_call, pool_alloc, pool_release};
-        aln_use_device_inflate(&ops);
+        const aln_device_ops ops = {g_inflater,       itx_bamwin_push,  itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
+                                    itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    pool_alloc,       pool_release,     itx_last_error};
+        aln_use_device(&ops);
     }
     /* table: every chromosome of the size file is known to the engine (a read may land on one without repeats) */
     const uint32_t n_chrom = chr_sizes->names.n;

@@ -214,7 +214,7 @@ int itx_engine_get_stats(itx_engine *e, itx_stats *out);
  * bgzf_read -> bgzf_read_block, bgzf.c:425-521). The caller indexes the blocks of a chunk of the file (header
  * check bgzf.c:401-411, BSIZE, ISIZE trailer) and hands over the compressed chunk; every block is decoded by one
  * wavefront into its place in `out`. Offsets are relative to `comp` / `out`; uoff must be the running sum of the
- * usize's (the inflated bytes are contiguous). `comp` needs 8 readable bytes past comp_len. status[i] = 0 when block
+ * usize's (the inflated bytes are contiguous). `comp` needs 16 readable bytes past comp_len. status[i] = 0 when block
  * i inflated to exactly usize bytes, else a small positive code (the data is damaged or the decoder declined it —
  * the caller's zlib has the last word, as in the reference). Synchronous; one calling thread per inflater. */
 typedef struct itx_inflater itx_inflater;

@@ -13,6 +13,7 @@
 #define ITXI_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(x)))
 #define ITXI_BCAST(v, j) ((uint32_t)__builtin_amdgcn_readlane((int32_t)(v), (int32_t)(j)))
 #define ITXI_AT(p, i) (p)[(i) * 64u + ln]          /* a decoder's table element i: lane-interleaved (bank = lane) */
+#define ITXI_BITREV32(x) __builtin_bitreverse32(x)
 #define ITXI_LOADW(w, i) ((w)[(i)])
 #define ITXI_LOADB(p, i) ((p)[(i)])
 // A far match reads bytes this wave stored earlier through other lanes. Workgroup scope is all it takes — the wave's
@@ -33,12 +34,12 @@
 __global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp, const itx_bgzf_block *__restrict__ blk, uint32_t n, uint8_t *__restrict__ lit,
                                                uint32_t *__restrict__ tok, uint32_t *__restrict__ meta)
 {
-    __shared__ uint16_t s_lsym[288 * 64], s_dsym[32 * 64], s_offs[16 * 64];
+    __shared__ uint16_t s_lsym[288 * 64], s_dsym[32 * 64], s_offs[16 * 64], s_loffs[16 * 64], s_doffs[16 * 64];
     __shared__ uint8_t s_lens[352 * 64];
     const uint32_t ln = threadIdx.x, b = blockIdx.x * 64u + ln;
     if (b >= n) return;
     const uint32_t coff = blk[b].coff, csize = blk[b].csize, usize = blk[b].usize;
-    ItxiTab T{s_lsym, s_dsym, s_offs, s_lens};
+    ItxiTab T{s_lsym, s_dsym, s_offs, s_loffs, s_doffs, s_lens};
     ItxiTokens K{lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, 0, 0};
     int rc = ITXI_E_INPUT;
     if (csize >= BGZF_HEADER + BGZF_TRAILER + 2u && usize <= ITXI_MAX_BLOCK)

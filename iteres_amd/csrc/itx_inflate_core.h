@@ -28,7 +28,7 @@
 // Hooks the including file defines: ITXI_FN (function attributes), ITXI_WAVE (lanes that share pass 2: 64 / 1),
 // ITXI_UNI(x) (pass 2: a wave-uniform value as such), ITXI_AT(p, i) (pass 1: element i of a per-decoder table: lane-
 // interleaved on the device, using the lane id `ln` in scope), ITXI_BCAST(v, j) (pass 2: lane j's v, for all),
-// ITXI_LOADW / ITXI_LOADB (global loads), ITXI_FENCE().
+// ITXI_BITREV32(x), ITXI_LOADW / ITXI_LOADB (global loads), ITXI_FENCE().
 #pragma once
 #include <stdint.h>
 
@@ -58,12 +58,15 @@ enum {
 
 struct ItxiTab {                           // one decoder's tables (element i through ITXI_AT)
     uint16_t *lsym, *dsym;                 // [288], [32]: symbols in canonical order (by code length, then symbol)
-    uint16_t *offs;                        // [16]
+    uint16_t *offs;                        // [16]: scratch of the counting sort
+    uint16_t *loffs, *doffs;               // [16] each: itxi_decode's per-length offsets of the two codes in use
     uint8_t *lens;                         // [352]: code lengths being set up: literal/length at 0, distance at 288, code-length code at 320
 };
 
-struct ItxiCodes {                         // counts per code length 1..15, two to a word (length 2k+1 low, 2k+2 high)
-    uint32_t c[8];
+struct ItxiCodes {
+    // lim[l - 1]: every code of length <= l, written MSB first and left-aligned to 15 bits, is below this bound (the bounds
+    // rise with l; lim[14] < 2^15 exactly when the code is incomplete)
+    uint32_t lim[15];
 };
 
 struct ItxiIn {
@@ -71,6 +74,7 @@ struct ItxiIn {
     uint32_t ip, end;                      // next word to load; byte offset of the first byte past the block's data
     uint64_t bb;                           // bit buffer, next bit in bit 0
     uint32_t bn;                           // valid bits in bb
+    uint32_t nw;                           // word ip, loaded ahead of its use: the next load is in flight while symbols decode
 };
 
 ITXI_FN void itxi_in_start(ItxiIn &in, uint32_t byte_pos)
@@ -80,16 +84,18 @@ ITXI_FN void itxi_in_start(ItxiIn &in, uint32_t byte_pos)
     in.bb = (uint64_t)(ITXI_LOADW(in.w, in.ip) >> skip);
     in.ip++;
     in.bn = 32u - skip;
+    in.nw = ITXI_LOADW(in.w, in.ip);
 }
 
-// at least 33 valid bits afterwards; reading a few words past the end is harmless (the caller pads the buffer), consuming
+// at least 33 valid bits afterwards; reading a few words past the end is harmless (the caller pads the buffer by 16 bytes), consuming
 // them is caught by the callers through itxi_overrun
 ITXI_FN void itxi_refill(ItxiIn &in)
 {
     if (in.bn <= 32u) {
-        in.bb |= (uint64_t)ITXI_LOADW(in.w, in.ip) << in.bn;
+        in.bb |= (uint64_t)in.nw << in.bn;
         in.ip++;
         in.bn += 32u;
+        in.nw = ITXI_LOADW(in.w, in.ip);
     }
 }
 
@@ -107,34 +113,27 @@ ITXI_FN bool itxi_overrun(const ItxiIn &in)                 // a bit of a byte a
     return in.ip * 4u - (in.bn >> 3) > in.end;
 }
 
-// One symbol of a canonical code (puff.c decode()): codes of each length are consecutive integers, shorter codes first.
-// `peek` holds the next 15 stream bits; returns the symbol's index in canonical order and its length, or len = 0.
-// Branch-free over the 15 lengths: the lanes of a wave decode different codes, so every length is visited anyway.
-ITXI_FN uint32_t itxi_decode(const ItxiCodes &h, uint32_t peek, uint32_t &len_out)
+// One symbol of a canonical code: codes of each length are consecutive integers, shorter codes first (RFC 1951 3.2.2), so
+// with the next 15 stream bits read MSB first as the number v, the code's length is 1 + the number of bounds v has
+// reached — fifteen independent compares instead of puff.c's bit-by-bit walk (one wave per SIMD: a dependent chain
+// costs its full latency) — and its place in canonical order is v's leading `len` bits plus a per-length offset
+// (`offs`, filled by itxi_construct). Returns that place and the length, or len = 0 for a pattern that is no code.
+ITXI_FN uint32_t itxi_decode(const ItxiCodes &h, const uint16_t *offs, uint32_t ln, uint32_t peek, uint32_t &len_out)
 {
-    int32_t code = 0, first = 0, index = 0;
-    uint32_t len_found = 0, at = 0;
+    (void)ln;
+    const uint32_t v = ITXI_BITREV32(peek) >> 17;                  // 15 bits, first stream bit on top
+    uint32_t len = 1;
 #pragma unroll
-    for (int len = 1; len <= 15; len++) {
-        code |= (int32_t)(peek & 1u);
-        peek >>= 1;
-        const uint32_t word = h.c[(len - 1) >> 1];
-        const int32_t count = (int32_t)(((len - 1) & 1) ? word >> 16 : word & 0xffffu);
-        const bool hit = len_found == 0 && code - count < first;
-        at = hit ? (uint32_t)(index + (code - first)) : at;
-        len_found = hit ? (uint32_t)len : len_found;
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
-    }
-    len_out = len_found;
+    for (int l = 0; l < 14; l++) len += v >= h.lim[l] ? 1u : 0u;
+    const bool ok = v < h.lim[14];
+    const uint32_t at = (uint32_t)(uint16_t)(ITXI_AT(offs, len) + (v >> (15u - len)));
+    len_out = ok ? len : 0u;
     return at;
 }
 
 // Counting sort of `n` code lengths (T.lens[base ..]) into canonical order (puff.c construct()). Returns 0 for a complete
 // code, > 0 for an incomplete one (bits left over), < 0 for an over-subscribed one.
-ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint16_t *sym, uint32_t base, uint32_t n, uint32_t &n_zero_or_one)
+ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint16_t *sym, uint16_t *offs_out, uint32_t base, uint32_t n, uint32_t &n_zero_or_one)
 {
     (void)ln;
     uint32_t cnt[16];
@@ -167,8 +166,16 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint
             ITXI_AT(T.offs, l) = (uint16_t)(at + 1u);
         }
     }
+    // what itxi_decode wants: the bounds, and per length (place of its first code) - (its first code), mod 2^16
+    uint32_t first = 0, index = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) h.c[k] = cnt[2 * k + 1] | ((2 * k + 2 <= 15 ? cnt[2 * k + 2] : 0u) << 16);
+    for (int len = 1; len <= 15; len++) {
+        ITXI_AT(offs_out, len) = (uint16_t)(index - first);
+        index += cnt[len];
+        first += cnt[len];
+        h.lim[len - 1] = first << (15 - len);
+        first <<= 1;
+    }
     return left;
 }
 
@@ -183,10 +190,6 @@ struct ItxiTokens {
 
 ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_words, uint32_t data_pos, uint32_t data_end, uint32_t usize, ItxiTokens &K)
 {
-    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     static const uint8_t clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
     ItxiIn in;
@@ -243,7 +246,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
                 ItxiCodes cc;
                 uint32_t n01;
-                if (itxi_construct(T, ln, cc, T.lsym, 320, 19, n01) != 0) return ITXI_E_CODES;         // must be complete
+                if (itxi_construct(T, ln, cc, T.lsym, T.loffs, 320, 19, n01) != 0) return ITXI_E_CODES;         // must be complete
                 // code lengths of the literal/length and distance codes, run-length coded as ONE sequence (a run may
                 // cross from one code into the other); entry idx of it lives at place(idx)
 #define ITXI_PLACE(i) ((i) < nl ? (i) : 288u + ((i) - nl))
@@ -251,7 +254,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 while (idx < nl + nd) {
                     itxi_refill(in);
                     uint32_t cl;
-                    const uint32_t at = itxi_decode(cc, (uint32_t)in.bb & 0x7fffu, cl);
+                    const uint32_t at = itxi_decode(cc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);
                     if (cl == 0) return ITXI_E_SYMBOL;
                     itxi_bits(in, cl);
                     const uint32_t sym = ITXI_AT(T.lsym, at);
@@ -279,15 +282,15 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (ITXI_AT(T.lens, 256) == 0) return ITXI_E_CODES;                              // no end-of-block code
             }
             uint32_t n01;
-            int32_t left = itxi_construct(T, ln, lc, T.lsym, 0, nl, n01);
+            int32_t left = itxi_construct(T, ln, lc, T.lsym, T.loffs, 0, nl, n01);
             if (type == 2 && left != 0 && (left < 0 || nl != n01)) return ITXI_E_CODES;          // the fixed code is incomplete by definition
-            left = itxi_construct(T, ln, dc, T.dsym, 288, nd, n01);
+            left = itxi_construct(T, ln, dc, T.dsym, T.doffs, 288, nd, n01);
             if (type == 2 && left != 0 && (left < 0 || nd != n01)) return ITXI_E_CODES;
 
             for (;;) {                                             // one symbol per turn; each produces output or ends the block
                 itxi_refill(in);
                 uint32_t cl;
-                uint32_t at = itxi_decode(lc, (uint32_t)in.bb & 0x7fffu, cl);
+                uint32_t at = itxi_decode(lc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);
                 if (cl == 0) return ITXI_E_SYMBOL;
                 itxi_bits(in, cl);
                 const uint32_t sym = ITXI_AT(T.lsym, at);
@@ -302,14 +305,21 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (sym == 256u) break;
                 const uint32_t li = sym - 257u;
                 if (li >= 29u) return ITXI_E_SYMBOL;
-                const uint32_t len = lbase[li] + itxi_bits(in, lext[li]);
+                // RFC 1951 3.2.5 as arithmetic (a table lookup here is a dependent global load per lane: measured 1 us each):
+                // length codes 257..264 stand for 3..10; then groups of four share 1, 2, .. 5 extra bits; 285 is 258
+                const uint32_t le = (li < 8u || li == 28u) ? 0u : (li - 4u) >> 2;
+                const uint32_t lb = li < 8u ? 3u + li : li == 28u ? 258u : 3u + ((4u + (li & 3u)) << le);
+                const uint32_t len = lb + itxi_bits(in, le);
                 itxi_refill(in);
-                at = itxi_decode(dc, (uint32_t)in.bb & 0x7fffu, cl);
+                at = itxi_decode(dc, T.doffs, ln, (uint32_t)in.bb & 0x7fffu, cl);
                 if (cl == 0) return ITXI_E_SYMBOL;
                 itxi_bits(in, cl);
                 const uint32_t di = ITXI_AT(T.dsym, at);
                 if (di >= 30u) return ITXI_E_SYMBOL;
-                const uint32_t dist = dbase[di] + itxi_bits(in, dext[di]);
+                // distance codes 0..3 stand for 1..4; then pairs share 1, 2, .. 13 extra bits
+                const uint32_t de = di < 4u ? 0u : (di - 2u) >> 1;
+                const uint32_t db = di < 4u ? 1u + di : 1u + ((2u + (di & 1u)) << de);
+                const uint32_t dist = db + itxi_bits(in, de);
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
                 if (dist > produced) return ITXI_E_DIST;
                 if (len > usize - produced) return ITXI_E_OUTPUT;

@@ -7,6 +7,15 @@
 #define ITXI_FN static inline
 #define ITXI_UNI(x) (x)
 #define ITXI_BCAST(v, j) (v)
+static inline uint32_t itxi_bitrev32(uint32_t x)
+{
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+}
+#define ITXI_BITREV32(x) itxi_bitrev32(x)
 #define ITXI_AT(p, i) (p)[(i)]
 #define ITXI_LOADW(w, i) ((w)[i])
 #define ITXI_LOADB(p, i) ((p)[i])
@@ -16,14 +25,14 @@
 extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, uint32_t data_end, uint8_t *out, uint32_t g0, uint32_t usize,
                                 uint32_t *n_lit, uint32_t *n_tok)
 {
-    static thread_local uint16_t lsym[288], dsym[32], offs[16];
+    static thread_local uint16_t lsym[288], dsym[32], offs[16], loffs[16], doffs[16];
     static thread_local uint8_t lens[352];
     static thread_local uint32_t ring32[ITXI_RING / 4], stage32[ITXI_LSTAGE / 4];
     static thread_local std::vector<uint32_t> lit32(ITXI_MAX_BLOCK / 4 + 4);
     uint8_t *lit = reinterpret_cast<uint8_t *>(lit32.data());
     static thread_local std::vector<uint32_t> tok(2 * ITXI_MAX_TOK);
     if (usize > ITXI_MAX_BLOCK) return ITXI_E_OUTPUT;
-    ItxiTab T{lsym, dsym, offs, lens};
+    ItxiTab T{lsym, dsym, offs, loffs, doffs, lens};
     ItxiTokens K{lit, tok.data(), 0, 0};
     int rc = itxi_tokens(T, 0, comp_words, data_pos, data_end, usize, K);
     if (n_lit) *n_lit = K.n_lit;

@@ -156,6 +156,11 @@ int itx_engine_wait_slot(itx_engine *e, int slot);
  * device int32[n] (16-byte aligned) for the chosen rows. Returns after enqueueing. Submissions of one
  * engine must be stream-ordered with respect to each other. */
 int itx_engine_submit_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
+/* The same on the engine's own compute stream (the one the slot submits run on: device batches and slot batches of one
+ * record stream stay ordered). itx_engine_wait_own returns when everything submitted there is through — the arrays of
+ * `b` may then be reused — without waiting for other work on the device. */
+int itx_engine_submit_device_own(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row);
+int itx_engine_wait_own(itx_engine *e);
 /* Classification only (no accumulation): cuskent/binRange.c:196-227 + generic.c:950-970 per record. */
 int itx_engine_classify_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream);
 /* The lookup alone, on plain intervals: for record i the FIRST row binKeeperFind(chrom of tid[i], pos[i], tmpend[i])
@@ -244,6 +249,9 @@ int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve
  *   fetch     records [first, first + n) of the last parse into dst's HOST arrays at index dst_at (hit_row untouched),
  *             optionally their byte offsets in the window and per-record XA marks
  *   bytes     raw window bytes at such offsets (read names, XA / NM strings: the caller's side channels)
+ *   tids      which references (tid < n_targets) have a mapped record in the last parsed window (one byte each)
+ *   device_batch  records [first, ..) of the last parse as DEVICE arrays for itx_engine_submit_device* (first % 16 == 0;
+ *             valid until the next parse)
  * Records are located by guess-and-verify (csrc/itx_inflate.hip): exact whatever the bytes look like. A record of
  * more than 4 MiB that straddles two chunks is beyond this path (ITX_E_LIMIT). One thread may push while another
  * parses / fetches the OTHER window. */
@@ -257,6 +265,8 @@ int itx_bamwin_skip(itx_inflater *h, int w, size_t n);
 int itx_bamwin_parse(itx_inflater *h, int w, int n_targets, size_t *n_rec, int *malformed, int *flags, size_t *rewalked);
 int itx_bamwin_fetch(itx_inflater *h, size_t first, size_t n, const itx_staging *dst, size_t dst_at, uint32_t *rec_off, uint8_t *xa);
 int itx_bamwin_bytes(itx_inflater *h, size_t off, void *dst, size_t len);
+int itx_bamwin_tids(itx_inflater *h, uint8_t *seen, int n_targets);
+int itx_bamwin_device_batch(itx_inflater *h, size_t first, int with_mates, itx_batch *out);
 
 /* Page-locked host memory for the buffers that cross PCIe on every call (NULL when it cannot be had). */
 void *itx_pinned_alloc(size_t bytes);

@@ -380,6 +380,35 @@ extern "C" int itx_engine_submit_device(itx_engine *e, const itx_batch *b, size_
     return run_batch(e, to_dev_batch(b), n, d_hit_row, (hipStream_t)stream, RUN_ACCUMULATE);
 }
 
+/* The same on the engine's OWN compute stream — the one the slot submits run on — so that device batches and slot batches of
+ * one stream of records stay ordered; itx_engine_wait_own returns when everything submitted there is through (the arrays of
+ * `b` may then be reused) without waiting for other work on the device. */
+extern "C" int itx_engine_submit_device_own(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row)
+{
+    if (!e || !b || (n && (!b->tid || !b->pos || !b->tmpend || !b->mapq || !b->flag5)) || ((b->mpos == nullptr) != (b->isize == nullptr))) {
+        itx_set_error("itx_engine_submit_device_own: bad argument");
+        return ITX_E_ARG;
+    }
+    int rc = use_device(e);
+    if (rc) return rc;
+    rc = ensure_slots(e);
+    if (rc) return rc;
+    if (n > e->cap) {
+        itx_set_error("itx_engine_submit_device_own: %zu records exceed the batch capacity %zu", n, e->cap);
+        return ITX_E_ARG;
+    }
+    return run_batch(e, to_dev_batch(b), n, d_hit_row, e->compute, RUN_ACCUMULATE);
+}
+
+extern "C" int itx_engine_wait_own(itx_engine *e)
+{
+    if (!e) return ITX_E_ARG;
+    int rc = use_device(e);
+    if (rc) return rc;
+    if (e->slots_ready) ITX_HIP(hipStreamSynchronize(e->compute));
+    return ITX_OK;
+}
+
 extern "C" int itx_engine_classify_device(itx_engine *e, const itx_batch *b, size_t n, int32_t *d_hit_row, void *stream)
 {
     if (!e || !b || !d_hit_row || (n && (!b->tid || !b->pos || !b->tmpend || !b->mapq || !b->flag5))) {

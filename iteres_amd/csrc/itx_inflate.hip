@@ -210,7 +210,8 @@ static __device__ inline bool has_xa(const uint8_t *s, const uint8_t *end)
 // one thread per record: the fields generic.c:745-905 reads, bam_calend (bam.c:17-27: M, D, N advance) or pos + l_qseq
 __global__ __launch_bounds__(256) void k_parse(const uint8_t *__restrict__ u, const uint32_t *__restrict__ rec_off, uint32_t n, int32_t *__restrict__ tid_o,
                                                int32_t *__restrict__ pos_o, int32_t *__restrict__ end_o, uint8_t *__restrict__ mapq_o, uint8_t *__restrict__ f5_o,
-                                               int32_t *__restrict__ mpos_o, int32_t *__restrict__ isize_o, uint8_t *__restrict__ xa_o, uint32_t *__restrict__ flags)
+                                               int32_t *__restrict__ mpos_o, int32_t *__restrict__ isize_o, uint8_t *__restrict__ xa_o, uint32_t *__restrict__ flags,
+                                               uint8_t *__restrict__ seen, int32_t n_targets)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool paired = false, xa = false;
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t *__restrict__ u, co
         mpos_o[i] = mpos;
         isize_o[i] = isize;
         paired = flag & 1u;
+        if (!(flag & 4u) && tid >= 0 && tid < n_targets) seen[tid] = 1;          /* a mapped record on this reference (generic.c:764,781) */
         const uint64_t ql = l_qseq > 0 ? (uint64_t)l_qseq : 0;
         const uint64_t off = (uint64_t)l_qname + 4ull * n_cigar + (ql + 1) / 2 + ql;
         xa = off < dlen && has_xa(data + off, data + dlen);
@@ -271,6 +273,8 @@ struct itx_inflater {
     size_t h_blk_cap;
     void *d_sum, *h_sum;                   // PieceSum per piece, and its host copy
     uint32_t *d_spec, *d_pb, *h_pb, *d_recoff, *d_flags;
+    uint8_t *d_seen;
+    size_t seen_cap;
     size_t sum_cap, spec_cap, pb_cap, recoff_cap, soa_cap;
     int32_t *d_tid, *d_pos, *d_end, *d_mpos, *d_isize;
     uint8_t *d_mapq, *d_f5, *d_xa;
@@ -323,6 +327,7 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_pb);
     (void)hipFree(h->d_recoff);
     (void)hipFree(h->d_flags);
+    (void)hipFree(h->d_seen);
     (void)hipFree(h->d_tid);
     (void)hipFree(h->d_pos);
     (void)hipFree(h->d_end);
@@ -585,6 +590,8 @@ extern "C" int itx_bamwin_parse(itx_inflater *h, int w, int n_targets, size_t *n
     }
     if ((rc = grow(&h->d_spec, &h->spec_cap, (size_t)T * PIECE_SLOTS)) != ITX_OK) return rc;
     if (!h->d_flags) INF_HIP(hipMalloc((void **)&h->d_flags, 16));
+    if ((rc = grow(&h->d_seen, &h->seen_cap, (size_t)(n_targets > 0 ? n_targets : 1))) != ITX_OK) return rc;
+    INF_HIP(hipMemsetAsync(h->d_seen, 0, (size_t)(n_targets > 0 ? n_targets : 1), st));
     PieceSum *d_sum = (PieceSum *)h->d_sum, *sum = (PieceSum *)h->h_sum;
     const uint8_t *u = h->win[w].buf;
     hipLaunchKernelGGL(k_guess, dim3((T + 63) / 64), dim3(64), 0, st, u, p0, L, T, (int32_t)n_targets, d_sum, h->d_spec);
@@ -642,7 +649,7 @@ extern "C" int itx_bamwin_parse(itx_inflater *h, int w, int n_targets, size_t *n
     hipLaunchKernelGGL(k_compact, dim3(T), dim3(64), 0, st, h->d_spec, h->d_pb, h->d_pb + T, T, h->d_recoff);
     INF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_parse, dim3((tot + 255) / 256), dim3(256), 0, st, u, h->d_recoff, tot, h->d_tid, h->d_pos, h->d_end, h->d_mapq, h->d_f5, h->d_mpos, h->d_isize,
-                       h->d_xa, h->d_flags);
+                       h->d_xa, h->d_flags, h->d_seen, (int32_t)n_targets);
     INF_HIP(hipGetLastError());
     uint32_t fl = 0;
     INF_HIP(hipMemcpyAsync(&fl, h->d_flags, 4, hipMemcpyDeviceToHost, st));
@@ -685,5 +692,26 @@ extern "C" int itx_bamwin_bytes(itx_inflater *h, size_t off, void *dst, size_t l
     if (off + len > h->win[w].cap) return ITX_E_ARG;
     INF_HIP(hipSetDevice(h->device));
     if (len) INF_HIP(hipMemcpy(dst, h->win[w].buf + off, len, hipMemcpyDeviceToHost));
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_tids(itx_inflater *h, uint8_t *seen, int n_targets)
+{
+    if (!h || !seen || n_targets < 0 || (size_t)n_targets > h->seen_cap) return ITX_E_ARG;
+    INF_HIP(hipSetDevice(h->device));
+    if (n_targets) INF_HIP(hipMemcpy(seen, h->d_seen, (size_t)n_targets, hipMemcpyDeviceToHost));
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_device_batch(itx_inflater *h, size_t first, int with_mates, itx_batch *out)
+{
+    if (!h || !out || first > h->n_rec || (first & 15u)) return ITX_E_ARG;
+    out->tid = h->d_tid + first;
+    out->pos = h->d_pos + first;
+    out->tmpend = h->d_end + first;
+    out->mapq = h->d_mapq + first;
+    out->flag5 = h->d_f5 + first;
+    out->mpos = with_mates ? h->d_mpos + first : nullptr;
+    out->isize = with_mates ? h->d_isize + first : nullptr;
     return ITX_OK;
 }

@@ -60,7 +60,8 @@ struct aln_reader {
     struct blk *blk;          /* block index of the chunk being inflated                                        */
     size_t blk_cap;
     /* device decoder (aln_use_device): two windows of inflated bytes live on the device, dw is the one being consumed */
-    int dev, dw, dparsed, dlast, dflags;
+    int dev, dw, dparsed, dlast, dflags, dseen_ok;
+    uint8_t *dseen;           /* references with a mapped record in the current window                             */
     size_t dn_rec, drec_next, d_rewalked;
     itx_bgzf_block *dblk;     /* block index of a chunk for the device, and its per-block verdicts                */
     uint8_t *dstatus;
@@ -682,6 +683,7 @@ void aln_close(aln_reader *r)
     free(r->dblk);
     free(r->dstatus);
     free(r->hdr);
+    free(r->dseen);
     free(r->d_off);
     free(r->d_xa);
     free(r->d_raw);
@@ -959,28 +961,61 @@ static void locate_records(aln_reader *r)
 /* The device decoder's batch: the records of the current window are located and parsed on the device in one go; a batch
  * is a slice of them copied into the staging arrays. Read names and XA / NM strings, when somebody wants them, are cut
  * out of the records' raw bytes, fetched for just the records concerned. */
+/* makes drec_next < dn_rec: parses the current window, moves on to the next one when it is used up; 0 at end of input */
+static int dev_ensure_records(aln_reader *r)
+{
+    if (!r->pf_on && !r->eof) pf_start(r);
+    while (r->drec_next == r->dn_rec) {
+        if (!r->dparsed) {
+            const double th = now_s();
+            int malformed = 0, flags = 0;
+            size_t redo = 0;
+            DEV_CHK(dev.parse(dev.ctx, r->dw, r->n_targets, &r->dn_rec, &malformed, &flags, &redo), "parse");
+            t_hop += now_s() - th;
+            r->dparsed = 1;
+            r->drec_next = 0;
+            r->d_rewalked += redo;
+            r->dflags = flags;
+            r->dseen_ok = 0;
+            if (malformed) r->dlast = 1;                       /* bam.c:186-190: nothing after this window counts */
+            continue;
+        }
+        if (r->dlast || r->eof) return 0;                      /* end of input (a truncated tail record is dropped) */
+        dev_advance(r);
+    }
+    return 1;
+}
+
+int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen)
+{
+    if (!r->dev || !dev_ensure_records(r) || r->drec_next != 0) return 0;
+    if (!r->dseen_ok) {
+        r->dseen = xrealloc(r->dseen, (size_t)r->n_targets + 1);
+        DEV_CHK(dev.tids(dev.ctx, r->dseen, r->n_targets), "tids");
+        r->dseen_ok = 1;
+    }
+    *flags = r->dflags;
+    *tid_seen = r->dseen;
+    return 1;
+}
+
+size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b)
+{
+    if (!r->dev || !dev_ensure_records(r)) return 0;
+    size_t m = r->dn_rec - r->drec_next;
+    if (m > cap) m = cap;
+    DEV_CHK(dev.device_batch(dev.ctx, r->drec_next, r->dflags & 1, b), "device_batch");
+    r->drec_next += m;
+    return m;
+}
+
 static size_t dev_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
     size_t n = 0;
-    if (!r->pf_on && !r->eof) pf_start(r);
     while (n < cap) {
         if (r->drec_next == r->dn_rec) {
-            if (!r->dparsed) {
-                const double th = now_s();
-                int malformed = 0, flags = 0;
-                size_t redo = 0;
-                DEV_CHK(dev.parse(dev.ctx, r->dw, r->n_targets, &r->dn_rec, &malformed, &flags, &redo), "parse");
-                t_hop += now_s() - th;
-                r->dparsed = 1;
-                r->drec_next = 0;
-                r->d_rewalked += redo;
-                r->dflags = flags;
-                if (malformed) r->dlast = 1;                       /* bam.c:186-190: nothing after this window counts */
-                continue;
-            }
-            if (r->dlast || r->eof) break;                         /* end of input (a truncated tail record is dropped) */
-            dev_advance(r);
-            continue;
+            if (n) break;                                          /* a batch stays inside one window */
+            if (!dev_ensure_records(r)) break;
         }
         size_t m = r->dn_rec - r->drec_next;
         if (m > cap - n) m = cap - n;
@@ -1017,24 +1052,11 @@ static size_t dev_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_sid
                     if (want_q || xa[i]) {
                         int a1 = 0, x1 = 0;
                         bam_parse_one(raw + (ro[i] - lo), n + (size_t)i, st, side, &a1, &x1);   /* the same field values again, plus the strings */
-                    } else {
-                        side->xa[n + (size_t)i] = NULL;
-                        side->nm[n + (size_t)i] = 0;
                     }
             }
-            if (side->want_aux)
-                for (size_t i = 0; i < m; i++)
-                    if (i < i0 || i >= i1) {
-                        side->xa[n + i] = NULL;
-                        side->nm[n + i] = 0;
-                    }
+            side->has_strings = 1;                 /* entries outside [i0, i1) were never written: still NULL */
         } else {
             DEV_CHK(dev.fetch(dev.ctx, r->drec_next, m, st, n, NULL, NULL), "fetch");
-            if (side && side->want_aux)
-                for (size_t i = 0; i < m; i++) {
-                    side->xa[n + i] = NULL;
-                    side->nm[n + i] = 0;
-                }
         }
         t_parse += now_s() - tp;
         if (r->dflags & 1) *any_paired = 1;
@@ -1048,6 +1070,7 @@ static size_t dev_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_sid
 static size_t bam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
     if (r->dev) return dev_read_batch(r, st, cap, side, any_paired, aux_xa);
+    if (side) side->has_strings = 1;
     size_t n = 0;
     if (!r->pf_on && !r->eof) pf_start(r);
     while (n < cap) {
@@ -1112,6 +1135,7 @@ static unsigned flag_from_chars(const char *s)
 
 static size_t sam_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_side *side, int *any_paired, int *aux_xa)
 {
+    if (side) side->has_strings = 1;
     size_t n = 0;
     while (n < cap) {
         ssize_t len;

@@ -84,11 +84,20 @@ typedef struct aln_device_ops {
     int (*parse)(itx_inflater *, int, int, size_t *, int *, int *, size_t *);
     int (*fetch)(itx_inflater *, size_t, size_t, const itx_staging *, size_t, uint32_t *, uint8_t *);
     int (*bytes)(itx_inflater *, size_t, void *, size_t);
+    int (*tids)(itx_inflater *, uint8_t *, int);
+    int (*device_batch)(itx_inflater *, size_t, int, itx_batch *);
     void *(*alloc)(size_t bytes);
     void (*release)(void *p);
     const char *(*last_error)(void);
 } aln_device_ops;
 void aln_use_device(const aln_device_ops *ops);
+/* Device decoder only. aln_device_window: 1 when the next records can be taken as DEVICE arrays — the reader stands at
+ * the start of a decoded window (decoding the next one if need be); *flags: bit 0 some record of the window is paired,
+ * bit 1 some record carries an XA tag; *tid_seen[n_targets]: references with a mapped record in the window. 0: host
+ * decoder, end of input, or in the middle of a window: use aln_read_batch (which then stops at the window's end).
+ * aln_read_batch_device: the next <= cap records of that window as device arrays, valid until the next reader call. */
+int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen);
+size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b);
 aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the file cannot be opened / has no header */
 void aln_close(aln_reader *r);
 int aln_n_targets(const aln_reader *r);
@@ -96,6 +105,7 @@ const char *aln_target_name(const aln_reader *r, int tid);
 /* What the decoder keeps per record beside the SoA, when the caller wants it (arrays of the batch capacity). */
 typedef struct {
     int want_qnames, want_aux;
+    int has_strings;           /* set by the reader when the batch left any string behind (else every entry is still NULL)       */
     char **qname;              /* malloc'd copies of the read names (filter -r, stat -B/-V)                              */
     char **xa;                 /* malloc'd value of the XA:Z tag, NULL when the record has none (bam_aux2Z, bam_aux.c:193) */
     int32_t *nm;               /* NM:i, 0 when absent (bam_aux2i, bam_aux.c:159-170)                                      */

@@ -6,6 +6,7 @@
 #include <omp.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 static int usage(void)
 {
@@ -32,12 +33,17 @@ int main(int argc, char *argv[])
         if (n > 16) n = 16;
         omp_set_num_threads(n > 0 ? n : 1);
     }
-    if (strcmp(argv[1], "stat") == 0) return main_stat(argc - 1, argv + 1);
-    else if (strcmp(argv[1], "filter") == 0) return main_filter(argc - 1, argv + 1);
-    else if (strcmp(argv[1], "cpgstat") == 0) return main_cpgstat(argc - 1, argv + 1);
-    else if (strcmp(argv[1], "cpgfilter") == 0) return main_cpgfilter(argc - 1, argv + 1);
+    int rc;
+    if (strcmp(argv[1], "stat") == 0) rc = main_stat(argc - 1, argv + 1);
+    else if (strcmp(argv[1], "filter") == 0) rc = main_filter(argc - 1, argv + 1);
+    else if (strcmp(argv[1], "cpgstat") == 0) rc = main_cpgstat(argc - 1, argv + 1);
+    else if (strcmp(argv[1], "cpgfilter") == 0) rc = main_cpgfilter(argc - 1, argv + 1);
     else {
         fprintf(stderr, "[iteres] unrecognized command '%s'\n", argv[1]);
         return 1;
     }
+    /* every output file is closed by now: leave without the HIP runtime's and the allocator's tear-down (gigabytes of
+     * device and page-locked memory to hand back one by one — the kernel does it in one go) */
+    fflush(NULL);
+    _exit(rc);
 }

@@ -137,6 +137,8 @@ static void collect_names(hit_names *hn, const itx_staging *st, aln_side *side, 
 
 static void side_release(aln_side *side, size_t n, int keep_qnames)
 {
+    if (!side->has_strings) return;                /* nothing was stored: the arrays are all NULL as they were */
+    side->has_strings = 0;
     for (size_t i = 0; i < n; i++) {
         if (side->want_qnames && !keep_qnames) {
             free(side->qname[i]);
@@ -163,7 +165,8 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
     if (g_inflater) {
         const aln_device_ops ops = {g_inflater,       itx_bamwin_push,  itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
-                                    itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    pool_alloc,       pool_release,     itx_last_error};
+                                    itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    itx_bamwin_tids,  itx_bamwin_device_batch,
+                                    pool_alloc,      pool_release,     itx_last_error};
         aln_use_device(&ops);
     }
     /* table: every chromosome of the size file is known to the engine (a read may land on one without repeats) */
@@ -280,7 +283,41 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         }
         int s = 0, any_paired = 0, aux_xa = 0;
         double t_wait = 0, t_read = 0, t_host = 0, t_submit = 0, tq;
+        /* Nothing per record is the host's business when no option asks for names, -R or bed lines: a window of records the
+         * device decoder parsed then goes to the engine where it lies, in HBM. What is left for the host to look at comes with
+         * the window — does a record carry an XA tag (the veto needs its strings: host route for that window), is a mapped
+         * record on a chromosome the size file lacks (the warning is per record, in file order: host route). */
+        const int handoff_ok = !dups && !bed_f && !bed_uniq_f && !want_qnames;
         for (;;) {
+            if (handoff_ok) {
+                int wfl = 0, direct = 1;
+                const uint8_t *seen = NULL;
+                tq = now_s();
+                if (aln_device_window(rd, &wfl, &seen)) {
+                    if (veto_on && (wfl & 2)) direct = 0;
+                    for (int t = 0; t < nt && direct; t++)
+                        if (seen[t] && t2c[t] == -1) direct = 0;
+                    if (direct) {
+                        int wfl2;
+                        do {
+                            itx_batch db;
+                            const size_t n = aln_read_batch_device(rd, BATCH_RECORDS, &db);
+                            t_read += now_s() - tq;
+                            if (n == 0) break;
+                            for (unsigned long long m = (ends / progress_every + 1) * progress_every; m <= ends + n; m += progress_every)
+                                fprintf(stderr, "\r* Processed read ends: %llu", m);
+                            ends += n;
+                            tq = now_s();
+                            chk(itx_engine_submit_device_own(eng, &db, n, NULL), "itx_engine_submit_device_own");
+                            chk(itx_engine_wait_own(eng), "itx_engine_wait_own");              /* the arrays are the decoder's again */
+                            t_submit += now_s() - tq;
+                            tq = now_s();
+                        } while (!aln_device_window(rd, &wfl2, &seen));                        /* until the next window's start (or the end) */
+                        continue;
+                    }
+                }
+                t_read += now_s() - tq;
+            }
             /* slot s: collect what its previous batch left behind, then refill */
             tq = now_s();
             chk(itx_engine_wait_slot(eng, s), "itx_engine_wait_slot");

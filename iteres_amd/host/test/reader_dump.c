@@ -23,7 +23,7 @@ int main(int argc, char **argv)
     st.tid = malloc(cap * 4); st.pos = malloc(cap * 4); st.tmpend = malloc(cap * 4); st.mapq = malloc(cap); st.flag5 = malloc(cap);
     st.mpos = malloc(cap * 4); st.isize = malloc(cap * 4); st.hit_row = malloc(cap * 4); st.capacity = cap;
     char **qn = calloc(cap, sizeof(char *));
-    aln_side side = {1, 0, qn, NULL, NULL};
+    aln_side side = {.want_qnames = 1, .qname = qn};
     int any_paired = 0, xa = 0;
     size_t n, total = 0;
     while ((n = aln_read_batch(r, &st, cap, &side, &any_paired, &xa)) > 0) {

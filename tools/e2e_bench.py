@@ -60,6 +60,19 @@ def main():
         tl = [l for l in pr.stderr.split("\n") if l.startswith("[itx timing]")]
         if tl:
             out[name]["phases"] = tl
+    # A/B inside one box: ITX_E2E_AB="VAR=1" runs the drop-in three more times each without and with that setting
+    ab = os.environ.get("ITX_E2E_AB")
+    if ab:
+        k, v = ab.split("=", 1)
+        walls = {"base": [], ab: []}
+        for rep in range(3):
+            for tag, e in (("base", env), (ab, dict(env, **{k: v}))):
+                wd = os.path.join(tmp, f"ab_{tag}_{rep}".replace("=", "_"))
+                os.makedirs(wd)
+                t1 = time.time()
+                subprocess.run([ours] + base + [os.path.join(tmp, "reads.bam")], cwd=wd, capture_output=True, text=True, env=e)
+                walls[tag].append(round(time.time() - t1, 3))
+        out["ab_walls_s"] = walls
     if "reference" in out and same_bam:
         same = {}
         for fn in sorted(os.listdir(os.path.join(tmp, "reference"))):

@@ -60,7 +60,7 @@ struct aln_reader {
     struct blk *blk;          /* block index of the chunk being inflated                                        */
     size_t blk_cap;
     /* device decoder (aln_use_device): two windows of inflated bytes live on the device, dw is the one being consumed */
-    int dev, dw, dparsed, dlast, dflags, dseen_ok;
+    int dev, dw, dparsed, dlast, dflags, dseen_ok, dmore;
     uint8_t *dseen;           /* references with a mapped record in the current window                             */
     size_t dn_rec, drec_next, d_rewalked;
     itx_bgzf_block *dblk;     /* block index of a chunk for the device, and its per-block verdicts                */
@@ -243,9 +243,11 @@ static size_t raw_next(aln_reader *r)
 }
 
 /* The complete BGZF blocks of the raw bytes at hand (bgzf.c:401-411 header check, BSIZE, the ISIZE trailer) into r->blk;
- * *poff = compressed bytes they take, *putot = bytes they inflate to. */
-static size_t index_blocks(aln_reader *r, size_t *poff, size_t *putot, int *pdamaged)
+ * *poff = compressed bytes they take, *putot = bytes they inflate to. At most max_blocks blocks / max_utot inflated bytes
+ * are taken (*pcapped: more complete blocks may follow in what is at hand). */
+static size_t index_blocks(aln_reader *r, size_t max_blocks, size_t max_utot, size_t *poff, size_t *putot, int *pdamaged, int *pcapped)
 {
+    *pcapped = 0;
     struct blk *bl = r->blk;
     size_t nb = 0, off = 0, utot = 0;
     int damaged = 0;
@@ -264,6 +266,10 @@ static size_t index_blocks(aln_reader *r, size_t *poff, size_t *putot, int *pdam
         const size_t usize = rd_u32_at(h + bsize - 4);
         if (usize > BGZF_MAX) {
             damaged = 1;
+            break;
+        }
+        if (nb == max_blocks || utot + usize > max_utot) {      /* enough for one go: the rest stays for the next */
+            *pcapped = 1;
             break;
         }
         if (nb == r->blk_cap) {
@@ -295,7 +301,8 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
     }
     size_t off = 0, utot = 0;
     int damaged = 0;
-    const size_t nb = index_blocks(r, &off, &utot, &damaged);
+    int capped = 0;
+    const size_t nb = index_blocks(r, SIZE_MAX, SIZE_MAX, &off, &utot, &damaged, &capped);
     struct blk *bl = r->blk;
     if (at + utot + 64 > *pcap) {
         const size_t old_cap = *pcap;
@@ -337,12 +344,23 @@ static void pf_request(aln_reader *r);
  * stream ends in front of it (bgzf.c:471-521). Returns the inflated bytes added. */
 static size_t dev_fill(aln_reader *r, int w, int *peof)
 {
+    /* a window takes at most this much (extremely compressible input inflates a chunk to many gigabytes; the device side
+     * counts in 32 bits and keeps a quarter megabyte of scratch per block) */
+    enum { DEV_MAX_BLOCKS = 16384, DEV_MAX_BYTES = 1u << 30 };
+    static size_t max_blocks;
+    if (!max_blocks) {
+        const char *e = getenv("ITX_DEV_WINDOW_BLOCKS");              /* tests: windows of a few blocks */
+        const long x = e ? atol(e) : 0;
+        max_blocks = x >= 1 ? (size_t)x : DEV_MAX_BLOCKS;
+    }
     double tq = now_s();
-    const size_t got = raw_next(r);
+    size_t got = 1;
+    if (!r->dmore) got = raw_next(r);                              /* complete blocks of the last raw chunk are still waiting */
     t_io += now_s() - tq;
     size_t off = 0, utot = 0, n_new = 0;
-    int damaged = 0;
-    const size_t nb = r->clen ? index_blocks(r, &off, &utot, &damaged) : 0;
+    int damaged = 0, capped = 0;
+    const size_t nb = r->clen ? index_blocks(r, max_blocks, DEV_MAX_BYTES, &off, &utot, &damaged, &capped) : 0;
+    r->dmore = capped;
     if (r->dblk_cap < nb + 1) {
         r->dblk_cap = nb + nb / 4 + 1;
         r->dblk = xrealloc(r->dblk, sizeof *r->dblk * r->dblk_cap);
@@ -637,6 +655,12 @@ aln_reader *aln_open(const char *path, int is_sam)
         rc = sam_read_header(r);
     } else {
         r->dev = dev.push != NULL;
+        if (r->dev)
+            for (int w = 0; w < 2; w++) {                          /* whatever an earlier file left unconsumed is not this file's */
+                size_t left = 0;
+                DEV_CHK(dev.avail(dev.ctx, w, &left), "avail");
+                DEV_CHK(dev.skip(dev.ctx, w, left), "skip");
+            }
         rc = bam_read_header(r);
         if (r->dev && rc == 0) {
             DEV_CHK(dev.skip(dev.ctx, r->dw, r->hdr_pos), "skip");                 /* the records start here */

@@ -62,7 +62,7 @@ def test_cli_matches_reference_files(case, run_name, exe, tmp_path):
             assert banner in err
 
 
-@pytest.mark.parametrize("env", [{"ITX_BGZF_CHUNK": "30000", "ITX_HOP_PIECE": "500"}, {"ITX_BGZF_CHUNK": "3000"}, {"ITX_HOST_INFLATE": "1"},
+@pytest.mark.parametrize("env", [{"ITX_BGZF_CHUNK": "30000", "ITX_HOP_PIECE": "500"}, {"ITX_BGZF_CHUNK": "3000"}, {"ITX_DEV_WINDOW_BLOCKS": "2"}, {"ITX_HOST_INFLATE": "1"},
                                  {"ITX_HOST_INFLATE": "1", "ITX_BGZF_CHUNK": "30000"}])
 def test_cli_decode_paths_agree(env, exe, tmp_path):
     """The decode side of the drop-in has several routes — BGZF blocks inflated on the device (default) or by the host's

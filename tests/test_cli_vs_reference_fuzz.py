@@ -154,3 +154,35 @@ def test_random_case_matches_reference_binary(seed, exe, tmp_path):
                 assert refio.bigwig_digest(b) == refio.bigwig_digest(a), f"{tag}: {fn} decodes differently"
             else:
                 assert a == b, f"{tag}: {fn} differs"
+
+
+def test_file_list_matches_reference_binary(exe, tmp_path):
+    """stat takes a comma-separated list of alignment files (generic.c:725): one engine, one set of counters, a fresh
+    header (and tid map) per file — and a decoder whose windows must not leak from one file into the next."""
+    chroms = [("chr1", 2_000_000), ("chr2", 700_000)]
+    t = synth.make_table(9001, chroms, 3000, n_names=80, n_fams=12, n_clas=5)
+    inp = tmp_path / "in"
+    inp.mkdir()
+    synth.write_sizes(str(inp / "chrom.sizes"), chroms)
+    synth.write_sizes(str(inp / "rep.sizes"), t.rep_len.items())
+    synth.write_rmsk(str(inp / "rmsk.txt"), t)
+    paths = []
+    for k, (hdr, n) in enumerate(((chroms, 20_000), (chroms[::-1] + [("chrUn", 5000)], 7_000), (chroms, 1))):
+        r = synth.make_reads(9100 + k, hdr, n, read_len=(30, 120), paired_frac=0.2)
+        p = str(inp / f"r{k}.bam")
+        synth.write_bam(p, r, with_seq=True, block=0xff00 if k != 1 else 5000)
+        paths.append(p)
+    outs = {}
+    for who, prog in (("ref", REF), ("new", exe)):
+        work = tmp_path / who
+        work.mkdir()
+        pr = subprocess.run([prog, "stat", "-w", "-o", "out", str(inp / "chrom.sizes"), str(inp / "rep.sizes"), str(inp / "rmsk.txt"), ",".join(paths)],
+                            cwd=work, capture_output=True, text=True, timeout=600)
+        assert pr.returncode == 0, pr.stderr[-1500:]
+        outs[who] = work
+    for fn in sorted(os.listdir(outs["ref"])):
+        a, b = (outs["ref"] / fn).read_bytes(), (outs["new"] / fn).read_bytes()
+        if fn.endswith(".bigWig"):
+            assert refio.bigwig_digest(b) == refio.bigwig_digest(a), fn
+        else:
+            assert a == b, fn

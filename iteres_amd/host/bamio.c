@@ -121,7 +121,7 @@ static uint8_t *buf_grow(uint8_t *old, size_t keep, size_t ncap)
     return p;
 }
 #define CHUNK_COMPRESSED_DEFAULT (48u << 20)
-#define CHUNK_COMPRESSED_DEVICE (128u << 20)     /* a lane per block on the device: it takes thousands of blocks to fill it */
+#define CHUNK_COMPRESSED_DEVICE ALN_DEVICE_CHUNK  /* a lane per block on the device: it takes thousands of blocks to fill it */
 /* compressed bytes read and inflated per step; ITX_BGZF_CHUNK overrides it (tests force many small steps) */
 static size_t chunk_compressed(void)
 {

@@ -91,6 +91,7 @@ typedef struct aln_device_ops {
     const char *(*last_error)(void);
 } aln_device_ops;
 void aln_use_device(const aln_device_ops *ops);
+#define ALN_DEVICE_CHUNK (128u << 20)       /* compressed bytes per chunk handed to the device decoder (ITX_BGZF_CHUNK overrides) */
 /* Device decoder only. aln_device_window: 1 when the next records can be taken as DEVICE arrays — the reader stands at
  * the start of a decoded window (decoding the next one if need be); *flags: bit 0 some record of the window is paired,
  * bit 1 some record carries an XA tag; *tid_seen[n_targets]: references with a mapped record in the window. 0: host

@@ -66,7 +66,9 @@ static void *warm_main(void *arg)
     const double b = now_s();
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(0, &g_inflater) == ITX_OK) {
         /* the two compressed chunks the reader alternates between */
-        static const size_t want[POOL_N] = {(128u << 20) + (1u << 17), (128u << 20) + (1u << 17)};
+        const char *ce = getenv("ITX_BGZF_CHUNK");
+        const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
+        const size_t want[POOL_N] = {chunk + (1u << 17), chunk + (1u << 17)};
         for (int i = 0; i < POOL_N; i++) {
             pool[i].p = itx_pinned_alloc(want[i]);
             pool[i].cap = pool[i].p ? want[i] : 0;

@@ -44,7 +44,10 @@ def main():
         subprocess.check_call([mk, os.path.join(tmp, "chrom.sizes"), str(ref_reads), os.path.join(tmp, "reads_ref.bam"), str(seq_len), "7"], env=env)
     out = {"n_reads": n_reads, "n_rows": n_rows, "seq_len": seq_len, "bam_MB": round(os.path.getsize(os.path.join(tmp, "reads.bam")) / 1e6, 1),
            "gen_s": round(time.time() - t0, 1), "host_threads": int(threads), "host_cores": os.cpu_count()}
-    base = ["stat", "-w", "-o", "out", os.path.join(tmp, "chrom.sizes"), os.path.join(tmp, "rep.sizes"), os.path.join(tmp, "rmsk.txt")]
+    # ITX_E2E_CMD: another command line head than `stat -w`, e.g. "filter -n Rep1" (BASELINE configs[4])
+    head = os.environ.get("ITX_E2E_CMD", "stat -w").split()
+    out["command"] = " ".join(head)
+    base = head + ["-o", "out", os.path.join(tmp, "chrom.sizes"), os.path.join(tmp, "rep.sizes"), os.path.join(tmp, "rmsk.txt")]
     runs = [("drop_in", ours, "reads.bam", n_reads)]
     if os.path.exists(ref) and ref_reads > 0:
         runs.append(("reference", ref, "reads.bam" if same_bam else "reads_ref.bam", ref_reads))

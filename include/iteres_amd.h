@@ -237,8 +237,8 @@ int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve
 /* ---- BAM records located and parsed on the device ---------------------------------------------------------------
  * Replaces bam_read1 (cussamtools/bam.c:179-210) and the field reads of the scan loop (generic.c:745-905 off
  * bam1_core_t, bam.h:169-177; bam_calend bam.c:17-27) for whole chunks: the inflated bytes never leave the device,
- * only the per-record SoA (the itx_staging arrays) comes back. An inflater holds two WINDOWS of inflated bytes (w = 0,
- * 1) so that one can be filled while the records of the other are still being fetched:
+ * only the per-record SoA (the itx_staging arrays) comes back. An inflater holds three WINDOWS of inflated bytes (w = 0,
+ * 1, 2) so that two can be filled while the records of the third are still being fetched:
  *   push      inflate the blocks of a chunk into window w (offsets as for itx_inflate_bgzf; *n_new = bytes added)
  *   patch     overwrite part of what push produced (a block the caller inflated itself); truncate: drop the end
  *   carry     move the unconsumed tail of window `from` (a partial record) in front of window `to`'s fresh bytes
@@ -256,6 +256,12 @@ int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve
  * more than 4 MiB that straddles two chunks is beyond this path (ITX_E_LIMIT). One thread may push while another
  * parses / fetches the OTHER window. */
 int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, uint8_t *status, size_t *n_new);
+/* push in two halves, for a caller that keeps two pushes going (s = 0, 1: each has its own stream and scratch, so the Huffman
+ * pass of one chunk runs beside the replay of the previous one): begin enqueues and returns; copied waits until `comp` may be
+ * reused; end waits for the push and delivers status / n_new. There are three windows (w = 0, 1, 2) for this. */
+int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk);
+int itx_bamwin_push_copied(itx_inflater *h, int s);
+int itx_bamwin_push_end(itx_inflater *h, int s, uint8_t *status, size_t *n_new);
 int itx_bamwin_patch(itx_inflater *h, int w, size_t uoff, const void *bytes, size_t len);
 int itx_bamwin_truncate(itx_inflater *h, int w, size_t n_new);
 int itx_bamwin_carry(itx_inflater *h, int from, int to);

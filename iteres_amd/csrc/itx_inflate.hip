@@ -268,9 +268,18 @@ struct itx_inflater {
         uint8_t *buf;
         size_t cap;
         uint32_t start, len, consumed;     // unconsumed bytes are buf[start, len); consumed: end of the last parsed record
-    } win[2];
-    itx_bgzf_block *h_blk;                 // a call's block list shifted to the window's offsets
-    size_t h_blk_cap;
+    } win[3];
+    // a push in flight: its own stream and scratch, so that the Huffman pass of one chunk runs beside the replay of the last
+    struct {
+        hipStream_t st;
+        hipEvent_t copied;                 // the compressed bytes have left the caller's buffer
+        uint8_t *d_comp, *d_status, *d_lit, *h_status;
+        uint32_t *d_tok, *d_meta;
+        itx_bgzf_block *d_blk, *h_blk;     // h_blk (page-locked): the block list shifted to the window's offsets
+        size_t comp_cap, status_cap, lit_cap, tok_cap, meta_cap, blk_cap, h_cap;
+        size_t n_blk, total;
+        int busy;
+    } lane[2];
     void *d_sum, *h_sum;                   // PieceSum per piece, and its host copy
     uint32_t *d_spec, *d_pb, *h_pb, *d_recoff, *d_flags;
     uint8_t *d_seen;
@@ -301,6 +310,10 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     h->device = device;
     for (int k = 0; k < 2; k++) INF_HIP(hipStreamCreateWithFlags(&h->st[k], hipStreamNonBlocking));
     for (int k = 0; k < 4; k++) INF_HIP(hipEventCreate(&h->ev[k]));
+    for (int k = 0; k < 2; k++) {
+        INF_HIP(hipStreamCreateWithFlags(&h->lane[k].st, hipStreamNonBlocking));
+        INF_HIP(hipEventCreateWithFlags(&h->lane[k].copied, hipEventDisableTiming));
+    }
     *out = h;
     return ITX_OK;
 }
@@ -321,7 +334,22 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_lit);
     (void)hipFree(h->d_tok);
     (void)hipFree(h->d_meta);
-    for (int k = 0; k < 2; k++) (void)hipFree(h->win[k].buf);
+    for (int k = 0; k < 3; k++) (void)hipFree(h->win[k].buf);
+    for (int k = 0; k < 2; k++) {
+        if (h->lane[k].st) {
+            (void)hipStreamSynchronize(h->lane[k].st);
+            (void)hipStreamDestroy(h->lane[k].st);
+        }
+        if (h->lane[k].copied) (void)hipEventDestroy(h->lane[k].copied);
+        (void)hipFree(h->lane[k].d_comp);
+        (void)hipFree(h->lane[k].d_status);
+        (void)hipFree(h->lane[k].d_lit);
+        (void)hipFree(h->lane[k].d_tok);
+        (void)hipFree(h->lane[k].d_meta);
+        (void)hipFree(h->lane[k].d_blk);
+        if (h->lane[k].h_blk) (void)hipHostFree(h->lane[k].h_blk);
+        if (h->lane[k].h_status) (void)hipHostFree(h->lane[k].h_status);
+    }
     (void)hipFree(h->d_sum);
     (void)hipFree(h->d_spec);
     (void)hipFree(h->d_pb);
@@ -338,7 +366,6 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_xa);
     if (h->h_sum) (void)hipHostFree(h->h_sum);
     if (h->h_pb) (void)hipHostFree(h->h_pb);
-    free(h->h_blk);
     for (int k = 0; k < 4; k++)
         if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     free(h);
@@ -450,10 +477,15 @@ static int check_blocks(const itx_bgzf_block *blk, size_t n_blk, size_t comp_len
     return ITX_OK;
 }
 
-extern "C" int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, uint8_t *status, size_t *n_new)
+#define BAD_W(w) ((w) < 0 || (w) > 2)
+
+/* push, first half: everything is enqueued on lane s's stream and the call returns; the caller's buffers are in use until
+ * itx_bamwin_push_copied (comp) / this call's return (blk) */
+extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk)
 {
-    if (!h || (w != 0 && w != 1) || !comp || !blk || !status || !n_new) return ITX_E_ARG;
-    *n_new = 0;
+    if (!h || BAD_W(w) || (s != 0 && s != 1) || !comp || !blk) return ITX_E_ARG;
+    auto &Ln = h->lane[s];
+    if (Ln.busy) return ITX_E_STATE;
     size_t total = 0;
     int rc = check_blocks(blk, n_blk, comp_len, &total);
     if (rc != ITX_OK) return rc;
@@ -462,45 +494,79 @@ extern "C" int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t 
     if ((rc = grow(&h->win[w].buf, &h->win[w].cap, WIN_HEAD + total + 64)) != ITX_OK) return rc;
     h->win[w].start = h->win[w].consumed = WIN_HEAD;
     h->win[w].len = WIN_HEAD + (uint32_t)total;
+    Ln.n_blk = n_blk;
+    Ln.total = total;
+    Ln.busy = 1;
     if (n_blk == 0) return ITX_OK;
-    if (h->h_blk_cap < n_blk) {
-        free(h->h_blk);
-        h->h_blk_cap = n_blk + n_blk / 4;
-        h->h_blk = (itx_bgzf_block *)malloc(h->h_blk_cap * sizeof *h->h_blk);
-        if (!h->h_blk) return ITX_E_NOMEM;
+    if (Ln.h_cap < n_blk) {
+        if (Ln.h_blk) (void)hipHostFree(Ln.h_blk);
+        if (Ln.h_status) (void)hipHostFree(Ln.h_status);
+        Ln.h_blk = nullptr;
+        Ln.h_status = nullptr;
+        Ln.h_cap = 0;
+        const size_t want = n_blk + n_blk / 4 + 64;
+        INF_HIP(hipHostMalloc((void **)&Ln.h_blk, want * sizeof(itx_bgzf_block), hipHostMallocDefault));
+        INF_HIP(hipHostMalloc((void **)&Ln.h_status, want, hipHostMallocDefault));
+        Ln.h_cap = want;
     }
     for (size_t i = 0; i < n_blk; i++) {
-        h->h_blk[i] = blk[i];
-        h->h_blk[i].uoff += WIN_HEAD;
+        Ln.h_blk[i] = blk[i];
+        Ln.h_blk[i].uoff += WIN_HEAD;
     }
-    if ((rc = grow(&h->d_comp, &h->comp_cap, comp_len + 64)) != ITX_OK) return rc;
-    if ((rc = grow(&h->d_status, &h->status_cap, n_blk)) != ITX_OK) return rc;
-    if ((rc = grow(&h->d_blk, &h->blk_cap, n_blk)) != ITX_OK) return rc;
-    if ((rc = grow(&h->d_lit, &h->lit_cap, n_blk * (size_t)LIT_STRIDE)) != ITX_OK) return rc;
-    if ((rc = grow(&h->d_tok, &h->tok_cap, n_blk * (size_t)TOK_STRIDE)) != ITX_OK) return rc;
-    if ((rc = grow(&h->d_meta, &h->meta_cap, 3 * n_blk)) != ITX_OK) return rc;
-    hipStream_t st = h->st[0];
-    INF_HIP(hipMemcpyAsync(h->d_blk, h->h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, st));
-    INF_HIP(hipMemcpyAsync(h->d_comp, comp, comp_len, hipMemcpyHostToDevice, st));
-    INF_HIP(hipEventRecord(h->ev[0], st));
-    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)h->d_comp, h->d_blk, (uint32_t)n_blk, h->d_lit, h->d_tok,
-                       h->d_meta);
+    if ((rc = grow(&Ln.d_comp, &Ln.comp_cap, comp_len + 64)) != ITX_OK) return rc;
+    if ((rc = grow(&Ln.d_status, &Ln.status_cap, n_blk)) != ITX_OK) return rc;
+    if ((rc = grow(&Ln.d_blk, &Ln.blk_cap, n_blk)) != ITX_OK) return rc;
+    if ((rc = grow(&Ln.d_lit, &Ln.lit_cap, n_blk * (size_t)LIT_STRIDE)) != ITX_OK) return rc;
+    if ((rc = grow(&Ln.d_tok, &Ln.tok_cap, n_blk * (size_t)TOK_STRIDE)) != ITX_OK) return rc;
+    if ((rc = grow(&Ln.d_meta, &Ln.meta_cap, 3 * n_blk)) != ITX_OK) return rc;
+    hipStream_t st = Ln.st;
+    INF_HIP(hipMemcpyAsync(Ln.d_blk, Ln.h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, st));
+    INF_HIP(hipMemcpyAsync(Ln.d_comp, comp, comp_len, hipMemcpyHostToDevice, st));
+    INF_HIP(hipEventRecord(Ln.copied, st));
+    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta);
     INF_HIP(hipGetLastError());
-    INF_HIP(hipEventRecord(h->ev[1], st));
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, st, h->d_blk, 0u, (uint32_t)n_blk, h->d_lit, h->d_tok, h->d_meta, h->win[w].buf, h->d_status);
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, st, Ln.d_blk, 0u, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta, h->win[w].buf, Ln.d_status);
     INF_HIP(hipGetLastError());
-    INF_HIP(hipEventRecord(h->ev[2], st));
-    INF_HIP(hipMemcpyAsync(status, h->d_status, n_blk, hipMemcpyDeviceToHost, st));
-    INF_HIP(hipStreamSynchronize(st));
-    (void)hipEventElapsedTime(&h->ms_tokens, h->ev[0], h->ev[1]);
-    (void)hipEventElapsedTime(&h->ms_resolve, h->ev[1], h->ev[2]);
-    *n_new = total;
+    INF_HIP(hipMemcpyAsync(Ln.h_status, Ln.d_status, n_blk, hipMemcpyDeviceToHost, st));
     return ITX_OK;
+}
+
+/* the compressed bytes of lane s's push have been copied: the caller may reuse that buffer */
+extern "C" int itx_bamwin_push_copied(itx_inflater *h, int s)
+{
+    if (!h || (s != 0 && s != 1)) return ITX_E_ARG;
+    if (!h->lane[s].busy || h->lane[s].n_blk == 0) return ITX_OK;
+    INF_HIP(hipSetDevice(h->device));
+    INF_HIP(hipEventSynchronize(h->lane[s].copied));
+    return ITX_OK;
+}
+
+/* push, second half: waits for lane s's push; status[n_blk] as for itx_inflate_bgzf, *n_new = bytes the window gained */
+extern "C" int itx_bamwin_push_end(itx_inflater *h, int s, uint8_t *status, size_t *n_new)
+{
+    if (!h || (s != 0 && s != 1) || !status || !n_new) return ITX_E_ARG;
+    auto &Ln = h->lane[s];
+    if (!Ln.busy) return ITX_E_STATE;
+    INF_HIP(hipSetDevice(h->device));
+    INF_HIP(hipStreamSynchronize(Ln.st));
+    if (Ln.n_blk) memcpy(status, Ln.h_status, Ln.n_blk);
+    *n_new = Ln.total;
+    Ln.busy = 0;
+    return ITX_OK;
+}
+
+extern "C" int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, uint8_t *status, size_t *n_new)
+{
+    if (!status || !n_new) return ITX_E_ARG;
+    *n_new = 0;
+    int rc = itx_bamwin_push_begin(h, w, 0, comp, comp_len, blk, n_blk);
+    if (rc != ITX_OK) return rc;
+    return itx_bamwin_push_end(h, 0, status, n_new);
 }
 
 extern "C" int itx_bamwin_patch(itx_inflater *h, int w, size_t uoff, const void *bytes, size_t len)
 {
-    if (!h || (w != 0 && w != 1) || !bytes || WIN_HEAD + uoff + len > h->win[w].len) return ITX_E_ARG;
+    if (!h || BAD_W(w) || !bytes || WIN_HEAD + uoff + len > h->win[w].len) return ITX_E_ARG;
     INF_HIP(hipSetDevice(h->device));
     INF_HIP(hipMemcpy(h->win[w].buf + WIN_HEAD + uoff, bytes, len, hipMemcpyHostToDevice));
     return ITX_OK;
@@ -508,14 +574,14 @@ extern "C" int itx_bamwin_patch(itx_inflater *h, int w, size_t uoff, const void 
 
 extern "C" int itx_bamwin_truncate(itx_inflater *h, int w, size_t n_new)
 {
-    if (!h || (w != 0 && w != 1) || WIN_HEAD + n_new > h->win[w].len) return ITX_E_ARG;
+    if (!h || BAD_W(w) || WIN_HEAD + n_new > h->win[w].len) return ITX_E_ARG;
     h->win[w].len = WIN_HEAD + (uint32_t)n_new;
     return ITX_OK;
 }
 
 extern "C" int itx_bamwin_carry(itx_inflater *h, int from, int to)
 {
-    if (!h || (from != 0 && from != 1) || to != 1 - from) return ITX_E_ARG;
+    if (!h || BAD_W(from) || BAD_W(to) || from == to) return ITX_E_ARG;
     const uint32_t tail = h->win[from].len - h->win[from].consumed;
     if (tail > WIN_HEAD) {
         itx_set_error("a BAM record of more than %u bytes straddles two chunks: beyond the device decoder (ITX_HOST_INFLATE=1 reads such files)", WIN_HEAD);
@@ -534,7 +600,7 @@ extern "C" int itx_bamwin_carry(itx_inflater *h, int from, int to)
 
 extern "C" int itx_bamwin_avail(const itx_inflater *h, int w, size_t *bytes)
 {
-    if (!h || (w != 0 && w != 1) || !bytes) return ITX_E_ARG;
+    if (!h || BAD_W(w) || !bytes) return ITX_E_ARG;
     *bytes = h->win[w].len - h->win[w].consumed;
     return ITX_OK;
 }
@@ -542,7 +608,7 @@ extern "C" int itx_bamwin_avail(const itx_inflater *h, int w, size_t *bytes)
 /* bytes [off, off + len) of the window's unconsumed part, to the host */
 extern "C" int itx_bamwin_peek(itx_inflater *h, int w, size_t off, void *dst, size_t len)
 {
-    if (!h || (w != 0 && w != 1) || !dst || (size_t)h->win[w].consumed + off + len > h->win[w].len) return ITX_E_ARG;
+    if (!h || BAD_W(w) || !dst || (size_t)h->win[w].consumed + off + len > h->win[w].len) return ITX_E_ARG;
     INF_HIP(hipSetDevice(h->device));
     if (len) INF_HIP(hipMemcpy(dst, h->win[w].buf + h->win[w].consumed + off, len, hipMemcpyDeviceToHost));
     return ITX_OK;
@@ -550,7 +616,7 @@ extern "C" int itx_bamwin_peek(itx_inflater *h, int w, size_t off, void *dst, si
 
 extern "C" int itx_bamwin_skip(itx_inflater *h, int w, size_t n)
 {
-    if (!h || (w != 0 && w != 1) || (size_t)h->win[w].consumed + n > h->win[w].len) return ITX_E_ARG;
+    if (!h || BAD_W(w) || (size_t)h->win[w].consumed + n > h->win[w].len) return ITX_E_ARG;
     h->win[w].consumed += (uint32_t)n;
     h->win[w].start = h->win[w].consumed;
     return ITX_OK;
@@ -558,7 +624,7 @@ extern "C" int itx_bamwin_skip(itx_inflater *h, int w, size_t n)
 
 extern "C" int itx_bamwin_parse(itx_inflater *h, int w, int n_targets, size_t *n_rec, int *malformed, int *flags, size_t *rewalked)
 {
-    if (!h || (w != 0 && w != 1) || !n_rec || !malformed || !flags) return ITX_E_ARG;
+    if (!h || BAD_W(w) || !n_rec || !malformed || !flags) return ITX_E_ARG;
     *n_rec = 0;
     *malformed = 0;
     *flags = 0;

@@ -24,7 +24,7 @@ EXPORTS = [
     "itx_engine_classify_device", "itx_engine_first_hit_slot", "itx_engine_first_hit_device", "itx_engine_sync", "itx_engine_reset", "itx_engine_finish", "itx_engine_get_stats",
     "itx_engine_partial_size", "itx_engine_export_partial", "itx_engine_finish_partial",
     "itx_inflater_create", "itx_inflater_destroy", "itx_inflate_bgzf", "itx_inflater_last_ms", "itx_pinned_alloc", "itx_pinned_free",
-    "itx_bamwin_push", "itx_bamwin_patch", "itx_bamwin_truncate", "itx_bamwin_carry", "itx_bamwin_avail", "itx_bamwin_peek", "itx_bamwin_skip",
+    "itx_bamwin_push", "itx_bamwin_push_begin", "itx_bamwin_push_copied", "itx_bamwin_push_end", "itx_bamwin_patch", "itx_bamwin_truncate", "itx_bamwin_carry", "itx_bamwin_avail", "itx_bamwin_peek", "itx_bamwin_skip",
     "itx_bamwin_parse", "itx_bamwin_fetch", "itx_bamwin_bytes", "itx_bamwin_tids", "itx_bamwin_device_batch",
     "itx_engine_submit_device_own", "itx_engine_wait_own",
 ]

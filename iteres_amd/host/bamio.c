@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #define BGZF_MAX 0x10000
 
@@ -44,8 +46,11 @@ struct aln_reader {
     uint8_t *cbuf;            /* compressed bytes of the current chunk (+ the incomplete block carried over):   */
     size_t clen;              /* a window into one of the two raw buffers below                                 */
     /* raw read-ahead (raw_next): a reader thread freads the next compressed chunk while this one is being inflated */
-    uint8_t *craw[2];
+    uint8_t *craw[3];         /* two for the host decoder; three for the device's (a chunk's bytes stay until its push has ended) */
+    int n_raw;
     size_t io_got;
+    int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
+    size_t io_off, io_size;
     int io_on, io_state, io_stop, io_buf, io_done;   /* io_state: 0 idle, 1 requested, 2 ready; io_done: the file is read out */
     pthread_t io_thread;
     pthread_mutex_t io_mu;
@@ -60,7 +65,16 @@ struct aln_reader {
     struct blk *blk;          /* block index of the chunk being inflated                                        */
     size_t blk_cap;
     /* device decoder (aln_use_device): two windows of inflated bytes live on the device, dw is the one being consumed */
-    int dev, dw, dparsed, dlast, dflags, dseen_ok, dmore;
+    int dev, dw, dparsed, dlast, dflags, dseen_ok, dmore, dinput_done;
+    long dk_begin, dk_ready, dk_cur;   /* chunks whose push was begun / has ended; the chunk whose window is being consumed (-1 none) */
+    struct dev_job {
+        struct blk *bl;        /* the chunk's blocks and where its compressed bytes lie, kept until its push has ended */
+        size_t bl_cap, nb;
+        const uint8_t *cbase;
+        int w, last;
+    } dj[2];
+    size_t dring_n[3];
+    int dring_eof[3];
     uint8_t *dseen;           /* references with a mapped record in the current window                             */
     size_t dn_rec, drec_next, d_rewalked;
     itx_bgzf_block *dblk;     /* block index of a chunk for the device, and its per-block verdicts                */
@@ -86,7 +100,7 @@ struct aln_reader {
 };
 
 /* ---- BGZF ------------------------------------------------------------------------------------------------ */
-static aln_device_ops dev;                   /* .push == NULL: the host decodes */
+static aln_device_ops dev;                   /* .push_begin == NULL: the host decodes */
 void aln_use_device(const aln_device_ops *ops)
 {
     if (ops) dev = *ops;
@@ -129,7 +143,7 @@ static size_t chunk_compressed(void)
     if (!v) {
         const char *e = getenv("ITX_BGZF_CHUNK");
         const long x = e ? atol(e) : 0;
-        v = x >= 1 ? (size_t)x : dev.push ? CHUNK_COMPRESSED_DEVICE : CHUNK_COMPRESSED_DEFAULT;
+        v = x >= 1 ? (size_t)x : dev.push_begin ? CHUNK_COMPRESSED_DEVICE : CHUNK_COMPRESSED_DEFAULT;
     }
     return v;
 }
@@ -198,7 +212,36 @@ static void *io_main(void *arg)
         if (r->io_stop) break;
         uint8_t *dst = r->craw[r->io_buf] + RAW_HEAD;
         pthread_mutex_unlock(&r->io_mu);
-        const size_t got = fread(dst, 1, RAW_STEP, r->f);
+        size_t got;
+        if (r->io_fd >= 0) {
+            /* a regular file: the step is read as four slices at once (one thread copying out of the page cache delivers
+             * about 7 GB/s — less than the device decodes) */
+            const size_t step = RAW_STEP;
+            size_t want = r->io_size > r->io_off ? r->io_size - r->io_off : 0;
+            if (want > step) want = step;
+            const int parts = want >= (4u << 20) ? 4 : 1;
+            const size_t per = (want + (size_t)parts - 1) / (size_t)parts;
+            size_t done[4] = {0, 0, 0, 0};
+#pragma omp parallel for num_threads(parts) schedule(static, 1)
+            for (int q = 0; q < parts; q++) {
+                const size_t lo = (size_t)q * per, hi = lo + per < want ? lo + per : want;
+                size_t at = lo;
+                while (at < hi) {
+                    const ssize_t k = pread(r->io_fd, dst + at, hi - at, (off_t)(r->io_off + at));
+                    if (k <= 0) break;                             /* end of file or an error: what came before counts */
+                    at += (size_t)k;
+                }
+                done[q] = at - lo;
+            }
+            got = 0;
+            for (int q = 0; q < parts; q++) {
+                got += done[q];
+                if (done[q] < ((size_t)q * per + per < want ? per : want - (size_t)q * per)) break;     /* a short slice ends the stream there */
+            }
+            r->io_off += got;
+        } else {
+            got = fread(dst, 1, RAW_STEP, r->f);
+        }
         pthread_mutex_lock(&r->io_mu);
         r->io_got = got;
         r->io_state = 2;
@@ -213,7 +256,18 @@ static size_t raw_next(aln_reader *r)
 {
     if (r->io_done) return 0;
     if (!r->io_on) {
-        for (int k = 0; k < 2; k++) r->craw[k] = buf_alloc(RAW_HEAD + RAW_STEP + 64);
+        r->n_raw = r->dev ? 3 : 2;
+        {
+            struct stat sb;
+            const int fd = fileno(r->f);
+            r->io_fd = -1;
+            if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && ftello(r->f) == 0) {
+                r->io_fd = fd;
+                r->io_off = 0;
+                r->io_size = (size_t)sb.st_size;
+            }
+        }
+        for (int k = 0; k < r->n_raw; k++) r->craw[k] = buf_alloc(RAW_HEAD + RAW_STEP + 64);
         pthread_mutex_init(&r->io_mu, NULL);
         pthread_cond_init(&r->io_cv, NULL);
         r->io_buf = 0;
@@ -230,7 +284,7 @@ static size_t raw_next(aln_reader *r)
     if (r->clen) memcpy(nb + RAW_HEAD - r->clen, r->cbuf, r->clen);
     r->cbuf = nb + RAW_HEAD - r->clen;
     r->clen += got;
-    r->io_buf ^= 1;
+    r->io_buf = (r->io_buf + 1) % r->n_raw;
     if (got == RAW_STEP) {
         r->io_state = 1;                                          /* the other buffer is free: read on */
         pthread_cond_broadcast(&r->io_cv);
@@ -339,10 +393,12 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
 static void pf_request(aln_reader *r);
 
 /* ---- the device decoder (aln_use_device): this side only moves compressed bytes in ------------------------------------
- * Window w of the device receives the inflated blocks of the next raw chunk. A block the device decoder flags is given
- * to zlib here, whose verdict is the reference's: inflated after all, its bytes are patched in; not inflatable, the
- * stream ends in front of it (bgzf.c:471-521). Returns the inflated bytes added. */
-static size_t dev_fill(aln_reader *r, int w, int *peof)
+ * Chunk k of the file is pushed into window k % 3 of the device on lane k % 2 (a lane = a stream with its own scratch): two
+ * pushes are kept in flight, so the Huffman pass of one chunk — a lane per block, latency-bound, most of the chip idle —
+ * runs beside the token replay of the chunk before it. A block the device decoder flags is given to zlib here, whose verdict
+ * is the reference's: inflated after all, its bytes are patched in; not inflatable, the stream ends in front of it
+ * (bgzf.c:471-521). */
+static void dev_begin(aln_reader *r)
 {
     /* a window takes at most this much (extremely compressible input inflates a chunk to many gigabytes; the device side
      * counts in 32 bits and keeps a quarter megabyte of scratch per block) */
@@ -353,74 +409,141 @@ static size_t dev_fill(aln_reader *r, int w, int *peof)
         const long x = e ? atol(e) : 0;
         max_blocks = x >= 1 ? (size_t)x : DEV_MAX_BLOCKS;
     }
+    const long k = r->dk_begin;
+    struct dev_job *j = &r->dj[k & 1];
     double tq = now_s();
     size_t got = 1;
     if (!r->dmore) got = raw_next(r);                              /* complete blocks of the last raw chunk are still waiting */
     t_io += now_s() - tq;
-    size_t off = 0, utot = 0, n_new = 0;
+    size_t off = 0, utot = 0;
     int damaged = 0, capped = 0;
     const size_t nb = r->clen ? index_blocks(r, max_blocks, DEV_MAX_BYTES, &off, &utot, &damaged, &capped) : 0;
     r->dmore = capped;
+    if (j->bl_cap < nb + 1) {
+        j->bl_cap = nb + nb / 4 + 1;
+        j->bl = xrealloc(j->bl, sizeof *j->bl * j->bl_cap);
+    }
     if (r->dblk_cap < nb + 1) {
         r->dblk_cap = nb + nb / 4 + 1;
         r->dblk = xrealloc(r->dblk, sizeof *r->dblk * r->dblk_cap);
         r->dstatus = xrealloc(r->dstatus, r->dblk_cap);
     }
-    const struct blk *bl = r->blk;
     for (size_t i = 0; i < nb; i++) {
-        r->dblk[i].coff = (uint32_t)bl[i].coff;
-        r->dblk[i].csize = (uint32_t)bl[i].csize;
-        r->dblk[i].uoff = (uint32_t)bl[i].uoff;
-        r->dblk[i].usize = (uint32_t)bl[i].usize;
+        j->bl[i] = r->blk[i];
+        r->dblk[i].coff = (uint32_t)r->blk[i].coff;
+        r->dblk[i].csize = (uint32_t)r->blk[i].csize;
+        r->dblk[i].uoff = (uint32_t)r->blk[i].uoff;
+        r->dblk[i].usize = (uint32_t)r->blk[i].usize;
     }
-    tq = now_s();
+    j->nb = nb;
+    j->cbase = r->cbuf;
+    j->w = (int)(k % 3);
+    j->last = damaged || (got == 0 && nb == 0);
     static const uint8_t none[16];
-    DEV_CHK(dev.push(dev.ctx, w, r->clen ? r->cbuf : none, off, r->dblk, nb, r->dstatus, &n_new), "push");
-    for (size_t i = 0; i < nb; i++)
+    tq = now_s();
+    DEV_CHK(dev.push_begin(dev.ctx, j->w, (int)(k & 1), r->clen ? r->cbuf : none, off, r->dblk, nb), "push");
+    t_inflate += now_s() - tq;
+    r->cbuf += off;
+    r->clen -= off;
+    r->dk_begin = k + 1;
+}
+
+/* waits for the oldest push in flight and settles its flagged blocks; the caller publishes dk_ready */
+static void dev_end(aln_reader *r)
+{
+    const long k = r->dk_ready;
+    struct dev_job *j = &r->dj[k & 1];
+    size_t n_new = 0;
+    const double tq = now_s();
+    DEV_CHK(dev.push_end(dev.ctx, (int)(k & 1), r->dstatus, &n_new), "push");
+    int damaged = 0;
+    for (size_t i = 0; i < j->nb; i++)
         if (r->dstatus[i]) {
             uint8_t tmp[BGZF_MAX + 8];
-            if (inflate_block(r->cbuf + bl[i].coff, bl[i].csize, tmp, bl[i].usize) == 0) {
-                fprintf(stderr, "[iteres] note: BGZF block at chunk offset %zu declined by the device decoder (code %d), inflated by zlib\n", bl[i].coff, r->dstatus[i]);
-                DEV_CHK(dev.patch(dev.ctx, w, bl[i].uoff, tmp, bl[i].usize), "patch");
+            if (inflate_block(j->cbase + j->bl[i].coff, j->bl[i].csize, tmp, j->bl[i].usize) == 0) {
+                fprintf(stderr, "[iteres] note: BGZF block at chunk offset %zu declined by the device decoder (code %d), inflated by zlib\n", j->bl[i].coff,
+                        r->dstatus[i]);
+                DEV_CHK(dev.patch(dev.ctx, j->w, j->bl[i].uoff, tmp, j->bl[i].usize), "patch");
             } else {
-                DEV_CHK(dev.truncate(dev.ctx, w, bl[i].uoff), "truncate");
-                n_new = bl[i].uoff;
+                DEV_CHK(dev.truncate(dev.ctx, j->w, j->bl[i].uoff), "truncate");
+                n_new = j->bl[i].uoff;
                 damaged = 1;
                 break;
             }
         }
     t_inflate += now_s() - tq;
-    r->cbuf += off;
-    r->clen -= off;
-    if (damaged || (got == 0 && nb == 0)) *peof = 1;
-    return n_new;
+    r->dring_n[j->w] = n_new;
+    r->dring_eof[j->w] = j->last || damaged;
+}
+
+/* The producer (read-ahead thread): begin a push whenever a window and a lane are free and input is left, end the oldest
+ * one otherwise. */
+static void *dev_producer(void *arg)
+{
+    aln_reader *r = arg;
+    pthread_mutex_lock(&r->pf_mu);
+    for (;;) {
+        int act = 0;                                               /* 1 begin, 2 end */
+        while (!r->pf_stop) {
+            const long begun = r->dk_begin, ready = r->dk_ready, cur = r->dk_cur;
+            if (!r->dinput_done && begun - cur < 3 && begun - ready < 2) {
+                act = 1;
+                break;
+            }
+            if (begun > ready) {
+                act = 2;
+                break;
+            }
+            pthread_cond_wait(&r->pf_cv, &r->pf_mu);
+        }
+        if (r->pf_stop) break;
+        pthread_mutex_unlock(&r->pf_mu);
+        if (act == 1) {
+            dev_begin(r);
+            pthread_mutex_lock(&r->pf_mu);
+            if (r->dj[(r->dk_begin - 1) & 1].last) r->dinput_done = 1;
+        } else {
+            dev_end(r);
+            pthread_mutex_lock(&r->pf_mu);
+            if (r->dring_eof[r->dk_ready % 3]) r->dinput_done = 1;
+            r->dk_ready++;
+            pthread_cond_broadcast(&r->pf_cv);
+        }
+    }
+    pthread_mutex_unlock(&r->pf_mu);
+    return NULL;
 }
 
 /* The next window becomes the current one: the unconsumed tail (a partial record, or header bytes) moves in front of its
- * fresh bytes. Synchronous while the header is read, from the read-ahead thread afterwards. Returns bytes added. */
+ * fresh bytes. Synchronous while the header is read, fed by the producer afterwards. Returns bytes added. */
 static size_t dev_advance(aln_reader *r)
 {
     if (r->eof) return 0;
-    size_t n;
-    int eof = 0;
-    const int nxt = 1 - r->dw;
+    const long nxt = r->dk_cur + 1;
     if (!r->pf_on) {
-        n = dev_fill(r, nxt, &eof);
+        if (r->dk_begin <= nxt) dev_begin(r);
+        while (r->dk_ready <= nxt) {
+            dev_end(r);
+            r->dk_ready++;
+        }
     } else {
         pthread_mutex_lock(&r->pf_mu);
-        while (r->pf_state != 2) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
-        r->pf_state = 0;
+        while (r->dk_ready <= nxt) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
         pthread_mutex_unlock(&r->pf_mu);
-        n = r->nlen;
-        eof = r->n_eof;
     }
-    DEV_CHK(dev.carry(dev.ctx, r->dw, nxt), "carry");
-    r->dw = nxt;
+    const int w = (int)(nxt % 3);
+    if (r->dk_cur >= 0) DEV_CHK(dev.carry(dev.ctx, r->dw, w), "carry");
+    if (r->pf_on) pthread_mutex_lock(&r->pf_mu);
+    r->dk_cur = nxt;
+    if (r->pf_on) {
+        pthread_cond_broadcast(&r->pf_cv);                         /* the window left behind is free */
+        pthread_mutex_unlock(&r->pf_mu);
+    }
+    r->dw = w;
     r->dparsed = 0;
     r->dn_rec = r->drec_next = 0;
-    if (eof) r->eof = 1;
-    else if (r->pf_on) pf_request(r);
-    return n;
+    if (r->dring_eof[w]) r->eof = 1;
+    return r->dring_n[w];
 }
 
 /* sequential read of n bytes from the device window's front (header parsing): through a host copy fetched 1 MiB at a time */
@@ -461,13 +584,14 @@ static size_t dev_read(aln_reader *r, void *dst, size_t n)
 static void *pf_main(void *arg)
 {
     aln_reader *r = arg;
+    if (r->dev) return dev_producer(r);
     pthread_mutex_lock(&r->pf_mu);
     for (;;) {
         while (r->pf_state != 1 && !r->pf_stop) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
         if (r->pf_stop) break;
         pthread_mutex_unlock(&r->pf_mu);
         int eof = 0;
-        const size_t n = r->dev ? dev_fill(r, 1 - r->dw, &eof) : bgzf_inflate_chunk(r, &r->nbuf, &r->ncap, PF_HEAD, &eof);
+        const size_t n = bgzf_inflate_chunk(r, &r->nbuf, &r->ncap, PF_HEAD, &eof);
         pthread_mutex_lock(&r->pf_mu);
         r->nlen = n;
         r->n_eof = eof;
@@ -494,7 +618,7 @@ static void pf_start(aln_reader *r)
     r->pf_stop = 0;
     if (pthread_create(&r->pf_thread, NULL, pf_main, r) != 0) die("cannot start the BAM read-ahead thread");
     r->pf_on = 1;
-    if (!r->eof) pf_request(r);
+    if (!r->eof && !r->dev) pf_request(r);                        /* the device producer drives itself */
 }
 
 /* Makes more inflated bytes available behind the unconsumed ones. Returns the number of bytes added (0 at end of
@@ -654,9 +778,10 @@ aln_reader *aln_open(const char *path, int is_sam)
     if (is_sam) {
         rc = sam_read_header(r);
     } else {
-        r->dev = dev.push != NULL;
+        r->dev = dev.push_begin != NULL;
+        r->dk_cur = -1;
         if (r->dev)
-            for (int w = 0; w < 2; w++) {                          /* whatever an earlier file left unconsumed is not this file's */
+            for (int w = 0; w < 3; w++) {                          /* whatever an earlier file left unconsumed is not this file's */
                 size_t left = 0;
                 DEV_CHK(dev.avail(dev.ctx, w, &left), "avail");
                 DEV_CHK(dev.skip(dev.ctx, w, left), "skip");
@@ -685,12 +810,17 @@ void aln_close(aln_reader *r)
                 r->dev ? "device" : ld_state == 1 ? "libdeflate" : "zlib", t_inflate, t_hop, r->hop_pieces, r->hop_redone + r->d_rewalked, t_parse);
     if (r->pf_on) {
         pthread_mutex_lock(&r->pf_mu);
-        while (r->pf_state == 1) pthread_cond_wait(&r->pf_cv, &r->pf_mu);      /* let a chunk in flight land */
+        while (!r->dev && r->pf_state == 1) pthread_cond_wait(&r->pf_cv, &r->pf_mu);      /* let a chunk in flight land */
         r->pf_stop = 1;
         pthread_cond_broadcast(&r->pf_cv);
         pthread_mutex_unlock(&r->pf_mu);
         pthread_join(r->pf_thread, NULL);
     }
+    if (r->dev)
+        while (r->dk_ready < r->dk_begin) {                           /* pushes still in flight: the lanes must be idle for the next file */
+            dev_end(r);
+            r->dk_ready++;
+        }
     if (r->io_on) {
         pthread_mutex_lock(&r->io_mu);
         while (r->io_state == 1) pthread_cond_wait(&r->io_cv, &r->io_mu);      /* let a read in flight land */
@@ -700,12 +830,13 @@ void aln_close(aln_reader *r)
         pthread_join(r->io_thread, NULL);
     }
     if (r->f) fclose(r->f);
-    buf_free(r->craw[0]);
-    buf_free(r->craw[1]);
+    for (int k = 0; k < 3; k++) buf_free(r->craw[k]);
     buf_free(r->nbuf);
     free(r->blk);
     free(r->dblk);
     free(r->dstatus);
+    free(r->dj[0].bl);
+    free(r->dj[1].bl);
     free(r->hdr);
     free(r->dseen);
     free(r->d_off);

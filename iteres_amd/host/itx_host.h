@@ -74,7 +74,8 @@ typedef struct aln_reader aln_reader;
  * page-locked memory for the compressed chunks. NULL restores the host decoder. */
 typedef struct aln_device_ops {
     itx_inflater *ctx;
-    int (*push)(itx_inflater *, int, const void *, size_t, const itx_bgzf_block *, size_t, uint8_t *, size_t *);
+    int (*push_begin)(itx_inflater *, int, int, const void *, size_t, const itx_bgzf_block *, size_t);
+    int (*push_end)(itx_inflater *, int, uint8_t *, size_t *);
     int (*patch)(itx_inflater *, int, size_t, const void *, size_t);
     int (*truncate)(itx_inflater *, int, size_t);
     int (*carry)(itx_inflater *, int, int);

@@ -32,7 +32,7 @@ static int warm_on, warm_bam;
  * its time: the helper thread gets them ready while the main thread parses the rmsk file, and hands them out from this
  * little pool. */
 static itx_inflater *g_inflater;
-#define POOL_N 2
+#define POOL_N 3
 static struct { void *p; size_t cap; int used; } pool[POOL_N];
 static pthread_mutex_t pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static void *pool_alloc(size_t n)
@@ -65,10 +65,10 @@ static void *warm_main(void *arg)
     const int ndev = itx_device_count();
     const double b = now_s();
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(0, &g_inflater) == ITX_OK) {
-        /* the two compressed chunks the reader alternates between */
+        /* the three compressed chunks the reader rotates through (one being read, two being decoded) */
         const char *ce = getenv("ITX_BGZF_CHUNK");
         const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
-        const size_t want[POOL_N] = {chunk + (1u << 17), chunk + (1u << 17)};
+        const size_t want[POOL_N] = {chunk + (1u << 17), chunk + (1u << 17), chunk + (1u << 17)};
         for (int i = 0; i < POOL_N; i++) {
             pool[i].p = itx_pinned_alloc(want[i]);
             pool[i].cap = pool[i].p ? want[i] : 0;
@@ -166,7 +166,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     int ndev = itx_device_count();
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
     if (g_inflater) {
-        const aln_device_ops ops = {g_inflater,       itx_bamwin_push,  itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
+        const aln_device_ops ops = {g_inflater,       itx_bamwin_push_begin, itx_bamwin_push_end, itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
                                     itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    itx_bamwin_tids,  itx_bamwin_device_batch,
                                     pool_alloc,      pool_release,     itx_last_error};
         aln_use_device(&ops);

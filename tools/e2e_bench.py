@@ -76,6 +76,14 @@ def main():
                 subprocess.run([ours] + base + [os.path.join(tmp, "reads.bam")], cwd=wd, capture_output=True, text=True, env=e)
                 walls[tag].append(round(time.time() - t1, 3))
         out["ab_walls_s"] = walls
+    # ITX_E2E_ROCPROF=<dir>: the drop-in once more under rocprofv3 (kernel trace + stats) for the per-kernel times of a whole run
+    prof = os.environ.get("ITX_E2E_ROCPROF")
+    if prof:
+        wd = os.path.join(tmp, "prof")
+        os.makedirs(wd)
+        os.makedirs(prof, exist_ok=True)
+        subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.abspath(prof), "-o", "cli", "--", ours] + base
+                       + [os.path.join(tmp, "reads.bam")], cwd=wd, capture_output=True, text=True, env=env)
     if "reference" in out and same_bam:
         same = {}
         for fn in sorted(os.listdir(os.path.join(tmp, "reference"))):

@@ -186,3 +186,33 @@ def test_file_list_matches_reference_binary(exe, tmp_path):
             assert refio.bigwig_digest(b) == refio.bigwig_digest(a), fn
         else:
             assert a == b, fn
+
+
+def test_long_reads_match_reference_binary(exe, tmp_path):
+    """Records of tens of kilobytes (long reads): they span BGZF blocks and the decoder's 16 KiB pieces; -E 0 so that the
+    CIGAR end decides the interval on both strands."""
+    chroms = [("chr1", 30_000_000)]
+    t = synth.make_table(9201, chroms, 20_000, n_names=100, n_fams=12, n_clas=5)
+    r = synth.make_reads(9202, chroms, 1500, read_len=(5_000, 40_000), odd_cigar_frac=0.4)
+    inp = tmp_path / "in"
+    inp.mkdir()
+    synth.write_sizes(str(inp / "chrom.sizes"), chroms)
+    synth.write_sizes(str(inp / "rep.sizes"), t.rep_len.items())
+    synth.write_rmsk(str(inp / "rmsk.txt"), t)
+    aln = str(inp / "long.bam")
+    synth.write_bam(aln, r, with_seq=True)
+    for cmd, opts in (("stat", ["-w", "-E", "0"]), ("stat", ["-w"]), ("filter", ["-c", t.clas[0], "-r"])):
+        outs = {}
+        for who, prog in (("ref", REF), ("new", exe)):
+            work = tmp_path / f"{cmd}_{len(opts)}_{who}"
+            work.mkdir()
+            pr = subprocess.run([prog, cmd] + opts + ["-o", "out", str(inp / "chrom.sizes"), str(inp / "rep.sizes"), str(inp / "rmsk.txt"), aln], cwd=work,
+                                capture_output=True, text=True, timeout=600)
+            assert pr.returncode == 0, pr.stderr[-1500:]
+            outs[who] = work
+        for fn in sorted(os.listdir(outs["ref"])):
+            a, b = (outs["ref"] / fn).read_bytes(), (outs["new"] / fn).read_bytes()
+            if fn.endswith(".bigWig"):
+                assert refio.bigwig_digest(b) == refio.bigwig_digest(a), fn
+            else:
+                assert a == b, (cmd, opts, fn)

@@ -171,3 +171,24 @@ def test_malformed_length_ends_the_stream(win, tmp_path):
     res = win.read_all(comp, 1 << 30)
     assert res["malformed"]
     check(res, rd)
+
+
+def test_records_longer_than_a_piece_and_a_block(win, tmp_path):
+    """Long reads: records of tens of kilobytes reach over several 16 KiB pieces (pieces without any record start) and over
+    BGZF blocks; short ones in between."""
+    chroms = [("c1", 50_000_000)]
+    a = synth.make_reads(105, chroms, 300, read_len=(20_000, 45_000), odd_cigar_frac=0.5)
+    b = synth.make_reads(106, chroms, 3000, read_len=(30, 200))
+    # interleave by position: one sorted file
+    import dataclasses
+    order = np.lexsort((np.concatenate([a.pos, b.pos]), np.concatenate([a.tid, b.tid])))
+    cat = lambda x, y: np.concatenate([x, y])[order]
+    r = dataclasses.replace(a, tid=cat(a.tid, b.tid), pos=cat(a.pos, b.pos), flag=cat(a.flag, b.flag), mapq=cat(a.mapq, b.mapq), l_qseq=cat(a.l_qseq, b.l_qseq),
+                            mtid=cat(a.mtid, b.mtid), mpos=cat(a.mpos, b.mpos), isize=cat(a.isize, b.isize),
+                            cigars=[(a.cigars + b.cigars)[i] for i in order], qname=[(a.qname + [f"s{i}" for i in range(len(b))])[i] for i in order])
+    path = str(tmp_path / "long.bam")
+    synth.write_bam(path, r, with_seq=True)
+    header, rd = refio.read_bam(path)
+    comp = open(path, "rb").read()
+    for chunk in (1 << 30, 300_000):
+        check(win.read_all(comp, chunk), rd)

@@ -223,6 +223,8 @@ int itx_engine_get_stats(itx_engine *e, itx_stats *out);
  * i inflated to exactly usize bytes, else a small positive code (the data is damaged or the decoder declined it —
  * the caller's zlib has the last word, as in the reference). Synchronous; one calling thread per inflater. */
 typedef struct itx_inflater itx_inflater;
+#define ITX_BAMWIN_LANES 2        /* pushes that may be in flight at once (push_begin's s) */
+#define ITX_BAMWIN_WINDOWS 3      /* windows of inflated bytes (w): one being consumed beside the pushes in flight */
 typedef struct itx_bgzf_block {
     uint32_t coff, csize;         /* the whole gzip member: 18-byte header, deflate data, CRC32, ISIZE */
     uint32_t uoff, usize;
@@ -237,8 +239,8 @@ int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve
 /* ---- BAM records located and parsed on the device ---------------------------------------------------------------
  * Replaces bam_read1 (cussamtools/bam.c:179-210) and the field reads of the scan loop (generic.c:745-905 off
  * bam1_core_t, bam.h:169-177; bam_calend bam.c:17-27) for whole chunks: the inflated bytes never leave the device,
- * only the per-record SoA (the itx_staging arrays) comes back. An inflater holds three WINDOWS of inflated bytes (w = 0,
- * 1, 2) so that two can be filled while the records of the third are still being fetched:
+ * only the per-record SoA (the itx_staging arrays) comes back. An inflater holds ITX_BAMWIN_WINDOWS WINDOWS of inflated bytes
+ * (w) so that some can be filled while the records of another are still being fetched:
  *   push      inflate the blocks of a chunk into window w (offsets as for itx_inflate_bgzf; *n_new = bytes added)
  *   patch     overwrite part of what push produced (a block the caller inflated itself); truncate: drop the end
  *   carry     move the unconsumed tail of window `from` (a partial record) in front of window `to`'s fresh bytes
@@ -256,9 +258,9 @@ int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve
  * more than 4 MiB that straddles two chunks is beyond this path (ITX_E_LIMIT). One thread may push while another
  * parses / fetches the OTHER window. */
 int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, uint8_t *status, size_t *n_new);
-/* push in two halves, for a caller that keeps two pushes going (s = 0, 1: each has its own stream and scratch, so the Huffman
- * pass of one chunk runs beside the replay of the previous one): begin enqueues and returns; copied waits until `comp` may be
- * reused; end waits for the push and delivers status / n_new. There are three windows (w = 0, 1, 2) for this. */
+/* push in two halves, for a caller that keeps several pushes going (s < ITX_BAMWIN_LANES: each has its own stream and scratch,
+ * so the latency-bound Huffman pass of one chunk runs beside the replay of the previous ones): begin enqueues and returns;
+ * copied waits until `comp` may be reused; end waits for the push and delivers status / n_new. */
 int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk);
 int itx_bamwin_push_copied(itx_inflater *h, int s);
 int itx_bamwin_push_end(itx_inflater *h, int s, uint8_t *status, size_t *n_new);

@@ -268,7 +268,7 @@ struct itx_inflater {
         uint8_t *buf;
         size_t cap;
         uint32_t start, len, consumed;     // unconsumed bytes are buf[start, len); consumed: end of the last parsed record
-    } win[3];
+    } win[ITX_BAMWIN_WINDOWS];
     // a push in flight: its own stream and scratch, so that the Huffman pass of one chunk runs beside the replay of the last
     struct {
         hipStream_t st;
@@ -279,7 +279,7 @@ struct itx_inflater {
         size_t comp_cap, status_cap, lit_cap, tok_cap, meta_cap, blk_cap, h_cap;
         size_t n_blk, total;
         int busy;
-    } lane[2];
+    } lane[ITX_BAMWIN_LANES];
     void *d_sum, *h_sum;                   // PieceSum per piece, and its host copy
     uint32_t *d_spec, *d_pb, *h_pb, *d_recoff, *d_flags;
     uint8_t *d_seen;
@@ -310,7 +310,7 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     h->device = device;
     for (int k = 0; k < 2; k++) INF_HIP(hipStreamCreateWithFlags(&h->st[k], hipStreamNonBlocking));
     for (int k = 0; k < 4; k++) INF_HIP(hipEventCreate(&h->ev[k]));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
         INF_HIP(hipStreamCreateWithFlags(&h->lane[k].st, hipStreamNonBlocking));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].copied, hipEventDisableTiming));
     }
@@ -334,8 +334,8 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_lit);
     (void)hipFree(h->d_tok);
     (void)hipFree(h->d_meta);
-    for (int k = 0; k < 3; k++) (void)hipFree(h->win[k].buf);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < ITX_BAMWIN_WINDOWS; k++) (void)hipFree(h->win[k].buf);
+    for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
         if (h->lane[k].st) {
             (void)hipStreamSynchronize(h->lane[k].st);
             (void)hipStreamDestroy(h->lane[k].st);
@@ -477,13 +477,14 @@ static int check_blocks(const itx_bgzf_block *blk, size_t n_blk, size_t comp_len
     return ITX_OK;
 }
 
-#define BAD_W(w) ((w) < 0 || (w) > 2)
+#define BAD_W(w) ((w) < 0 || (w) >= ITX_BAMWIN_WINDOWS)
+#define BAD_S(s) ((s) < 0 || (s) >= ITX_BAMWIN_LANES)
 
 /* push, first half: everything is enqueued on lane s's stream and the call returns; the caller's buffers are in use until
  * itx_bamwin_push_copied (comp) / this call's return (blk) */
 extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk)
 {
-    if (!h || BAD_W(w) || (s != 0 && s != 1) || !comp || !blk) return ITX_E_ARG;
+    if (!h || BAD_W(w) || BAD_S(s) || !comp || !blk) return ITX_E_ARG;
     auto &Ln = h->lane[s];
     if (Ln.busy) return ITX_E_STATE;
     size_t total = 0;
@@ -534,7 +535,7 @@ extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *
 /* the compressed bytes of lane s's push have been copied: the caller may reuse that buffer */
 extern "C" int itx_bamwin_push_copied(itx_inflater *h, int s)
 {
-    if (!h || (s != 0 && s != 1)) return ITX_E_ARG;
+    if (!h || BAD_S(s)) return ITX_E_ARG;
     if (!h->lane[s].busy || h->lane[s].n_blk == 0) return ITX_OK;
     INF_HIP(hipSetDevice(h->device));
     INF_HIP(hipEventSynchronize(h->lane[s].copied));
@@ -544,7 +545,7 @@ extern "C" int itx_bamwin_push_copied(itx_inflater *h, int s)
 /* push, second half: waits for lane s's push; status[n_blk] as for itx_inflate_bgzf, *n_new = bytes the window gained */
 extern "C" int itx_bamwin_push_end(itx_inflater *h, int s, uint8_t *status, size_t *n_new)
 {
-    if (!h || (s != 0 && s != 1) || !status || !n_new) return ITX_E_ARG;
+    if (!h || BAD_S(s) || !status || !n_new) return ITX_E_ARG;
     auto &Ln = h->lane[s];
     if (!Ln.busy) return ITX_E_STATE;
     INF_HIP(hipSetDevice(h->device));

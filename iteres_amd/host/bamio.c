@@ -46,7 +46,7 @@ struct aln_reader {
     uint8_t *cbuf;            /* compressed bytes of the current chunk (+ the incomplete block carried over):   */
     size_t clen;              /* a window into one of the two raw buffers below                                 */
     /* raw read-ahead (raw_next): a reader thread freads the next compressed chunk while this one is being inflated */
-    uint8_t *craw[3];         /* two for the host decoder; three for the device's (a chunk's bytes stay until its push has ended) */
+    uint8_t *craw[ITX_BAMWIN_WINDOWS]; /* two for the host decoder; one per window for the device's (a chunk's bytes stay until its push has ended) */
     int n_raw;
     size_t io_got;
     int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
@@ -72,9 +72,9 @@ struct aln_reader {
         size_t bl_cap, nb;
         const uint8_t *cbase;
         int w, last;
-    } dj[2];
-    size_t dring_n[3];
-    int dring_eof[3];
+    } dj[ITX_BAMWIN_LANES];
+    size_t dring_n[ITX_BAMWIN_WINDOWS];
+    int dring_eof[ITX_BAMWIN_WINDOWS];
     uint8_t *dseen;           /* references with a mapped record in the current window                             */
     size_t dn_rec, drec_next, d_rewalked;
     itx_bgzf_block *dblk;     /* block index of a chunk for the device, and its per-block verdicts                */
@@ -256,7 +256,7 @@ static size_t raw_next(aln_reader *r)
 {
     if (r->io_done) return 0;
     if (!r->io_on) {
-        r->n_raw = r->dev ? 3 : 2;
+        r->n_raw = r->dev ? ITX_BAMWIN_WINDOWS : 2;
         {
             struct stat sb;
             const int fd = fileno(r->f);
@@ -393,8 +393,8 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
 static void pf_request(aln_reader *r);
 
 /* ---- the device decoder (aln_use_device): this side only moves compressed bytes in ------------------------------------
- * Chunk k of the file is pushed into window k % 3 of the device on lane k % 2 (a lane = a stream with its own scratch): two
- * pushes are kept in flight, so the Huffman pass of one chunk — a lane per block, latency-bound, most of the chip idle —
+ * Chunk k of the file is pushed into window k % ITX_BAMWIN_WINDOWS of the device on lane k % ITX_BAMWIN_LANES (a lane = a
+ * stream with its own scratch): that many pushes are kept in flight, so the Huffman pass of one chunk — a lane per block, latency-bound, most of the chip idle —
  * runs beside the token replay of the chunk before it. A block the device decoder flags is given to zlib here, whose verdict
  * is the reference's: inflated after all, its bytes are patched in; not inflatable, the stream ends in front of it
  * (bgzf.c:471-521). */
@@ -410,7 +410,7 @@ static void dev_begin(aln_reader *r)
         max_blocks = x >= 1 ? (size_t)x : DEV_MAX_BLOCKS;
     }
     const long k = r->dk_begin;
-    struct dev_job *j = &r->dj[k & 1];
+    struct dev_job *j = &r->dj[k % ITX_BAMWIN_LANES];
     double tq = now_s();
     size_t got = 1;
     if (!r->dmore) got = raw_next(r);                              /* complete blocks of the last raw chunk are still waiting */
@@ -437,11 +437,11 @@ static void dev_begin(aln_reader *r)
     }
     j->nb = nb;
     j->cbase = r->cbuf;
-    j->w = (int)(k % 3);
+    j->w = (int)(k % ITX_BAMWIN_WINDOWS);
     j->last = damaged || (got == 0 && nb == 0);
     static const uint8_t none[16];
     tq = now_s();
-    DEV_CHK(dev.push_begin(dev.ctx, j->w, (int)(k & 1), r->clen ? r->cbuf : none, off, r->dblk, nb), "push");
+    DEV_CHK(dev.push_begin(dev.ctx, j->w, (int)(k % ITX_BAMWIN_LANES), r->clen ? r->cbuf : none, off, r->dblk, nb), "push");
     t_inflate += now_s() - tq;
     r->cbuf += off;
     r->clen -= off;
@@ -452,10 +452,10 @@ static void dev_begin(aln_reader *r)
 static void dev_end(aln_reader *r)
 {
     const long k = r->dk_ready;
-    struct dev_job *j = &r->dj[k & 1];
+    struct dev_job *j = &r->dj[k % ITX_BAMWIN_LANES];
     size_t n_new = 0;
     const double tq = now_s();
-    DEV_CHK(dev.push_end(dev.ctx, (int)(k & 1), r->dstatus, &n_new), "push");
+    DEV_CHK(dev.push_end(dev.ctx, (int)(k % ITX_BAMWIN_LANES), r->dstatus, &n_new), "push");
     int damaged = 0;
     for (size_t i = 0; i < j->nb; i++)
         if (r->dstatus[i]) {
@@ -486,7 +486,7 @@ static void *dev_producer(void *arg)
         int act = 0;                                               /* 1 begin, 2 end */
         while (!r->pf_stop) {
             const long begun = r->dk_begin, ready = r->dk_ready, cur = r->dk_cur;
-            if (!r->dinput_done && begun - cur < 3 && begun - ready < 2) {
+            if (!r->dinput_done && begun - cur < ITX_BAMWIN_WINDOWS && begun - ready < ITX_BAMWIN_LANES) {
                 act = 1;
                 break;
             }
@@ -501,11 +501,11 @@ static void *dev_producer(void *arg)
         if (act == 1) {
             dev_begin(r);
             pthread_mutex_lock(&r->pf_mu);
-            if (r->dj[(r->dk_begin - 1) & 1].last) r->dinput_done = 1;
+            if (r->dj[(r->dk_begin - 1) % ITX_BAMWIN_LANES].last) r->dinput_done = 1;
         } else {
             dev_end(r);
             pthread_mutex_lock(&r->pf_mu);
-            if (r->dring_eof[r->dk_ready % 3]) r->dinput_done = 1;
+            if (r->dring_eof[r->dk_ready % ITX_BAMWIN_WINDOWS]) r->dinput_done = 1;
             r->dk_ready++;
             pthread_cond_broadcast(&r->pf_cv);
         }
@@ -531,7 +531,7 @@ static size_t dev_advance(aln_reader *r)
         while (r->dk_ready <= nxt) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
         pthread_mutex_unlock(&r->pf_mu);
     }
-    const int w = (int)(nxt % 3);
+    const int w = (int)(nxt % ITX_BAMWIN_WINDOWS);
     if (r->dk_cur >= 0) DEV_CHK(dev.carry(dev.ctx, r->dw, w), "carry");
     if (r->pf_on) pthread_mutex_lock(&r->pf_mu);
     r->dk_cur = nxt;
@@ -781,7 +781,7 @@ aln_reader *aln_open(const char *path, int is_sam)
         r->dev = dev.push_begin != NULL;
         r->dk_cur = -1;
         if (r->dev)
-            for (int w = 0; w < 3; w++) {                          /* whatever an earlier file left unconsumed is not this file's */
+            for (int w = 0; w < ITX_BAMWIN_WINDOWS; w++) {         /* whatever an earlier file left unconsumed is not this file's */
                 size_t left = 0;
                 DEV_CHK(dev.avail(dev.ctx, w, &left), "avail");
                 DEV_CHK(dev.skip(dev.ctx, w, left), "skip");
@@ -830,13 +830,12 @@ void aln_close(aln_reader *r)
         pthread_join(r->io_thread, NULL);
     }
     if (r->f) fclose(r->f);
-    for (int k = 0; k < 3; k++) buf_free(r->craw[k]);
+    for (int k = 0; k < ITX_BAMWIN_WINDOWS; k++) buf_free(r->craw[k]);
     buf_free(r->nbuf);
     free(r->blk);
     free(r->dblk);
     free(r->dstatus);
-    free(r->dj[0].bl);
-    free(r->dj[1].bl);
+    for (int k = 0; k < ITX_BAMWIN_LANES; k++) free(r->dj[k].bl);
     free(r->hdr);
     free(r->dseen);
     free(r->d_off);

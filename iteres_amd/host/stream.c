@@ -32,7 +32,7 @@ static int warm_on, warm_bam;
  * its time: the helper thread gets them ready while the main thread parses the rmsk file, and hands them out from this
  * little pool. */
 static itx_inflater *g_inflater;
-#define POOL_N 3
+#define POOL_N ITX_BAMWIN_WINDOWS
 static struct { void *p; size_t cap; int used; } pool[POOL_N];
 static pthread_mutex_t pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static void *pool_alloc(size_t n)
@@ -65,10 +65,11 @@ static void *warm_main(void *arg)
     const int ndev = itx_device_count();
     const double b = now_s();
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(0, &g_inflater) == ITX_OK) {
-        /* the three compressed chunks the reader rotates through (one being read, two being decoded) */
+        /* the compressed chunks the reader rotates through (one being read, the others being decoded) */
         const char *ce = getenv("ITX_BGZF_CHUNK");
         const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
-        const size_t want[POOL_N] = {chunk + (1u << 17), chunk + (1u << 17), chunk + (1u << 17)};
+        size_t want[POOL_N];
+        for (int i = 0; i < POOL_N; i++) want[i] = chunk + (1u << 17);
         for (int i = 0; i < POOL_N; i++) {
             pool[i].p = itx_pinned_alloc(want[i]);
             pool[i].cap = pool[i].p ? want[i] : 0;

@@ -128,7 +128,7 @@ ITXI_FN uint32_t itxi_decode(const ItxiCodes &h, const uint16_t *offs, uint32_t 
     const bool ok = v < h.lim[14];
     const uint32_t at = (uint32_t)(uint16_t)(ITXI_AT(offs, len) + (v >> (15u - len)));
     len_out = ok ? len : 0u;
-    return at;
+    return ok ? at : 0u;                                           // a pattern that is no code must not become a table index
 }
 
 // Counting sort of `n` code lengths (T.lens[base ..]) into canonical order (puff.c construct()). Returns 0 for a complete

@@ -130,12 +130,41 @@ static bw_sumlist reduce_sections(const bw_section *sec, const size_t *sec_of, c
         for (size_t k = sec_of[c]; k < sec_of[c + 1]; k++) {
             const uint32_t chrom_size = chroms[sec[k].chrom_id].size;
             uint32_t start = sec[k].start;
-            for (uint32_t i = 0; i < sec[k].item_count; i++) {
-                const double val = (double)sec[k].val[i];
-                const int size = 1;
-                const double sum = size * val;
-                add_to_summary(&L, sec[k].chrom_id, chrom_size, start, start + 1, (uint32_t)size, val, val, sum, sum * val, reduction);
-                start += 1;
+            /* bbiAddToSummary for one-base items, the arithmetic of add_to_summary spelled out for overlap == item size == 1
+             * (f = 1.0): same operations on the same float fields in the same order, without the call and its loop per base */
+            const float *vals = sec[k].val;
+            const uint32_t n_items = sec[k].item_count;
+            uint32_t i = 0;
+            while (i < n_items) {
+                if (start >= chrom_size) break;                         /* add_to_summary clips end to the chromosome: nothing is added */
+                bw_summary *sum = L.n ? &L.v[L.n - 1] : NULL;
+                if (!sum || sum->chrom_id != sec[k].chrom_id || sum->end <= start) {
+                    const double v0 = (double)vals[i];
+                    add_to_summary(&L, sec[k].chrom_id, chrom_size, start, start + 1, 1u, v0, v0, v0, v0 * v0, reduction);   /* opens the summary */
+                    start += 1;
+                    i++;
+                    continue;
+                }
+                /* the open summary takes every base up to its end */
+                uint32_t upto = sum->end - start;
+                if (upto > n_items - i) upto = n_items - i;
+                uint32_t vc = sum->valid_count;
+                float mn = sum->min_val, mx = sum->max_val, sd = sum->sum_data, sq = sum->sum_squares;
+                for (uint32_t j = 0; j < upto; j++) {
+                    const double val = (double)vals[i + j];
+                    vc = (uint32_t)((double)vc + 1.0);
+                    if (mn > val) mn = (float)val;
+                    if (mx < val) mx = (float)val;
+                    sd = (float)((double)sd + val);
+                    sq = (float)((double)sq + val * val);
+                }
+                sum->valid_count = vc;
+                sum->min_val = mn;
+                sum->max_val = mx;
+                sum->sum_data = sd;
+                sum->sum_squares = sq;
+                start += upto;
+                i += upto;
             }
         }
         parts[c] = L;
@@ -516,17 +545,23 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
     bw_sumlist sums[10];
     uint32_t reductions[10];
     for (;;) {
-        sums[0] = reduce_sections(sec, sec_of, chroms, n_names, initial_reduction);
-        uint64_t size = (uint64_t)sums[0].n * 32;
+        /* How many summaries a reduction gives needs no arithmetic on the values: every sequence is covered base by base from
+         * 0 to its size, so its summaries tile it in steps of the reduction (bbiWrite.c:381-395). The values are reduced once,
+         * with the reduction the loop settles on. */
+        uint64_t n_first = 0;
+        for (size_t c = 0; c < n_names; c++) n_first += ((uint64_t)chroms[c].size + (uint64_t)initial_reduction - 1) / (uint64_t)initial_reduction;
+        uint64_t size = n_first * 32;
         size *= 2;                                                             /* "summary not compressing as well as primary data" */
         if (size >= max_reduced && size != last_summary_size) {
             int next = (int)(1.1 * initial_reduction * (double)size / (double)max_reduced);
             if (next < initial_reduction * 2) next = initial_reduction * 2;
             initial_reduction = next;
-            free(sums[0].v);
             last_summary_size = size;
-        } else
+        } else {
+            sums[0] = reduce_sections(sec, sec_of, chroms, n_names, initial_reduction);
+            if ((uint64_t)sums[0].n != n_first) die("internal error: bigWig first zoom level has %zu summaries, %llu expected", sums[0].n, (unsigned long long)n_first);
             break;
+        }
     }
     int n_sums = 1;
     reductions[0] = (uint32_t)initial_reduction;

@@ -151,7 +151,7 @@ extern "C" void itx_engine_destroy(itx_engine *e)
             if (e->slot[s].copied) (void)hipEventDestroy(e->slot[s].copied);
             if (e->slot[s].done) (void)hipEventDestroy(e->slot[s].done);
         }
-    if (e->slots_ready && e->compute) (void)hipStreamDestroy(e->compute);
+    if (e->compute) (void)hipStreamDestroy(e->compute);
     void *bufs[] = {e->u64, e->u32, e->d_tidrec, e->p64, e->p32, e->d_counts, e->d_cov, e->d_cov_uniq, e->d_locus_out};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -200,11 +200,18 @@ extern "C" int itx_engine_set_tidmap(itx_engine *e, const int32_t *tid2chrom, in
     return ITX_OK;
 }
 
+static int ensure_compute(itx_engine *e)
+{
+    if (!e->compute) ITX_HIP(hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking));
+    return ITX_OK;
+}
+
 static int ensure_slots(itx_engine *e)
 {
     if (e->slots_ready) return ITX_OK;
     const size_t n = e->cap + ITX_STREAM_TILE;
-    ITX_HIP(hipStreamCreateWithFlags(&e->compute, hipStreamNonBlocking));
+    int rc0 = ensure_compute(e);
+    if (rc0) return rc0;
     for (int s = 0; s < 2; s++) {
         ItxSlot &S = e->slot[s];
         ITX_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
@@ -391,7 +398,7 @@ extern "C" int itx_engine_submit_device_own(itx_engine *e, const itx_batch *b, s
     }
     int rc = use_device(e);
     if (rc) return rc;
-    rc = ensure_slots(e);
+    rc = ensure_compute(e);                  /* the stream alone: a run that never takes the host route needs no pinned slots */
     if (rc) return rc;
     if (n > e->cap) {
         itx_set_error("itx_engine_submit_device_own: %zu records exceed the batch capacity %zu", n, e->cap);
@@ -405,7 +412,7 @@ extern "C" int itx_engine_wait_own(itx_engine *e)
     if (!e) return ITX_E_ARG;
     int rc = use_device(e);
     if (rc) return rc;
-    if (e->slots_ready) ITX_HIP(hipStreamSynchronize(e->compute));
+    if (e->compute) ITX_HIP(hipStreamSynchronize(e->compute));
     return ITX_OK;
 }
 

@@ -254,6 +254,13 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t *__restrict__ u, co
     if ((threadIdx.x & 63u) == 0 && (bp | bx)) atomicOr(flags, (bp ? 1u : 0u) | (bx ? 2u : 0u));
 }
 
+// launched once when an inflater is made: loading the library's code objects costs a tenth of a second, and the helper
+// thread that creates the inflater has it to spare
+__global__ void k_warm(uint32_t *p)
+{
+    if (p) *p = 0;
+}
+
 struct itx_inflater {
     int device;
     hipStream_t st[2];
@@ -314,6 +321,9 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
         INF_HIP(hipStreamCreateWithFlags(&h->lane[k].st, hipStreamNonBlocking));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].copied, hipEventDisableTiming));
     }
+    hipLaunchKernelGGL(k_warm, dim3(1), dim3(1), 0, h->st[0], (uint32_t *)nullptr);
+    INF_HIP(hipGetLastError());
+    INF_HIP(hipStreamSynchronize(h->st[0]));
     *out = h;
     return ITX_OK;
 }

@@ -1153,6 +1153,8 @@ int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen)
     return 1;
 }
 
+int aln_device_exhausted(aln_reader *r) { return r->dev && !dev_ensure_records(r); }
+
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b)
 {
     if (!r->dev || !dev_ensure_records(r)) return 0;

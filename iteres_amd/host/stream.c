@@ -197,9 +197,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     chk(itx_engine_create(tab, &p, BATCH_RECORDS, &eng), "itx_engine_create");
     clock_gettime(CLOCK_MONOTONIC, &ts1);
     if (timing) fprintf(stderr, "[itx timing] table build + engine %.3f s\n", (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec));
-    itx_staging st[2];
-    chk(itx_engine_staging(eng, 0, &st[0]), "itx_engine_staging");
-    chk(itx_engine_staging(eng, 1, &st[1]), "itx_engine_staging");
+    itx_staging st[2];                            /* the pinned slots of the host route, taken when a batch first goes that way */
+    int have_slots = 0;
+    memset(st, 0, sizeof st);
 
     /* what the host keeps per record beside the SoA */
     const int want_bed = o->bed_path || o->bed_uniq_path;
@@ -320,6 +320,12 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                     }
                 }
                 t_read += now_s() - tq;
+                if (aln_device_exhausted(rd)) break;
+            }
+            if (!have_slots) {
+                chk(itx_engine_staging(eng, 0, &st[0]), "itx_engine_staging");
+                chk(itx_engine_staging(eng, 1, &st[1]), "itx_engine_staging");
+                have_slots = 1;
             }
             /* slot s: collect what its previous batch left behind, then refill */
             tq = now_s();

@@ -267,7 +267,7 @@ static size_t raw_next(aln_reader *r)
                 r->io_size = (size_t)sb.st_size;
             }
         }
-        for (int k = 0; k < r->n_raw; k++) r->craw[k] = buf_alloc(RAW_HEAD + RAW_STEP + 64);
+        r->craw[0] = buf_alloc(RAW_HEAD + RAW_STEP + 64);          /* the others when the rotation first reaches them */
         pthread_mutex_init(&r->io_mu, NULL);
         pthread_cond_init(&r->io_cv, NULL);
         r->io_buf = 0;
@@ -286,6 +286,12 @@ static size_t raw_next(aln_reader *r)
     r->clen += got;
     r->io_buf = (r->io_buf + 1) % r->n_raw;
     if (got == RAW_STEP) {
+        if (!r->craw[r->io_buf]) {
+            pthread_mutex_unlock(&r->io_mu);                       /* page-locking a buffer takes a while: not under the lock */
+            uint8_t *fresh = buf_alloc(RAW_HEAD + RAW_STEP + 64);
+            pthread_mutex_lock(&r->io_mu);
+            r->craw[r->io_buf] = fresh;
+        }
         r->io_state = 1;                                          /* the other buffer is free: read on */
         pthread_cond_broadcast(&r->io_cv);
     } else {

@@ -70,7 +70,8 @@ static void *warm_main(void *arg)
         const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
         size_t want[POOL_N];
         for (int i = 0; i < POOL_N; i++) want[i] = chunk + (1u << 17);
-        for (int i = 0; i < POOL_N; i++) {
+        /* the first two now; the third is locked by the producer thread when it first needs it, beside the device's work */
+        for (int i = 0; i < 2 && i < POOL_N; i++) {
             pool[i].p = itx_pinned_alloc(want[i]);
             pool[i].cap = pool[i].p ? want[i] : 0;
         }

@@ -1159,6 +1159,11 @@ int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen)
     return 1;
 }
 
+void aln_readahead(aln_reader *r)
+{
+    if (!r->is_sam && !r->pf_on && !r->eof) pf_start(r);
+}
+
 int aln_device_exhausted(aln_reader *r) { return r->dev && !dev_ensure_records(r); }
 
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b)

@@ -100,7 +100,7 @@ int main_filter(int argc, char **argv)
         free(copy);
     }
 
-    gpu_warmup_start(!o.is_sam);
+    gpu_warmup_start(!o.is_sam, o.aln_arg, 0);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);

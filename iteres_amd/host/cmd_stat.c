@@ -129,7 +129,7 @@ int main_stat(int argc, char **argv)
 
     const int timing = getenv("ITX_TIMING") != NULL;
     const double t_begin = now_s();
-    gpu_warmup_start(!o.is_sam);
+    gpu_warmup_start(!o.is_sam, o.aln_arg, 1);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);

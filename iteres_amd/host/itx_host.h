@@ -100,7 +100,8 @@ void aln_use_device(const aln_device_ops *ops);
  * aln_read_batch_device: the next <= cap records of that window as device arrays, valid until the next reader call. */
 int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen);
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b);
-int aln_device_exhausted(aln_reader *r);     /* device decoder: 1 when no record is left */
+int aln_device_exhausted(aln_reader *r);
+void aln_readahead(aln_reader *r);            /* BAM: start decoding ahead of the first aln_read_batch */     /* device decoder: 1 when no record is left */
 aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the file cannot be opened / has no header */
 void aln_close(aln_reader *r);
 int aln_n_targets(const aln_reader *r);
@@ -153,7 +154,7 @@ char *filename_without_ext(const char *path);
 /* Runs the record loop (generic.c:700-1062 / 343-697) over one or more files through the engine.
  * progress_every: 100000 (stat, generic.c:760) or 10000 (filter, generic.c:397). want_qnames: per-locus read
  * names (filter -r): *locus_names[row] receives a comma-joined list in BAM order. */
-void gpu_warmup_start(int bam_input);  /* starts the HIP runtime on a helper thread (and, for BAM input, the device inflater with its
+void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file);  /* starts the HIP runtime on a helper thread (and, for BAM input, the device inflater with its
                                         * page-locked buffers); run_stream joins it */
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
                 unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names,

@@ -26,6 +26,8 @@ static double now_s(void)
 #include <pthread.h>
 static pthread_t warm_thread;
 static int warm_on, warm_bam;
+static char *warm_first;                      /* the first alignment file, opened (and decoded ahead) by the helper thread */
+static aln_reader *warm_reader;
 
 /* BAM input is decoded on the device (include/iteres_amd.h: itx_bamwin_*: blocks inflated, records located and parsed
  * there) unless ITX_HOST_INFLATE is set. The reader's compressed-chunk buffers then have to be page-locked, which takes
@@ -58,6 +60,14 @@ static void pool_release(void *p)
     itx_pinned_free(p);
 }
 
+static void use_device_reader(void)
+{
+    const aln_device_ops ops = {g_inflater,       itx_bamwin_push_begin, itx_bamwin_push_end, itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
+                                itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    itx_bamwin_tids,  itx_bamwin_device_batch,
+                                pool_alloc,      pool_release,     itx_last_error};
+    aln_use_device(&ops);
+}
+
 static void *warm_main(void *arg)
 {
     (void)arg;
@@ -76,13 +86,27 @@ static void *warm_main(void *arg)
             pool[i].cap = pool[i].p ? want[i] : 0;
         }
     }
+    const double c = now_s();
+    if (g_inflater && warm_first) {
+        /* the first file's header, and its first windows decoded while the main thread is still parsing the rmsk file; a
+         * file that does not open is left to run_stream, which reports it where the reference does */
+        use_device_reader();
+        warm_reader = aln_open(warm_first, 0);
+        if (warm_reader) aln_readahead(warm_reader);
+    }
     if (getenv("ITX_TIMING"))
-        fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s, device inflater + page-locked buffers %.3f s (helper thread)\n", b - a, now_s() - b);
+        fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s, device inflater + page-locked buffers %.3f s, first file opened %.3f s (helper thread)\n", b - a,
+                c - b, now_s() - c);
     return NULL;
 }
-void gpu_warmup_start(int bam_input)
+void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file)
 {
     warm_bam = bam_input;
+    if (bam_input && aln_arg) {
+        warm_first = xstrdup(aln_arg);
+        char *c = multi_file ? strchr(warm_first, ',') : NULL;
+        if (c) *c = 0;
+    }
     if (!warm_on && pthread_create(&warm_thread, NULL, warm_main, NULL) == 0) warm_on = 1;
 }
 static void gpu_warmup_join(void)
@@ -161,18 +185,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
 {
     const int timing = getenv("ITX_TIMING") != NULL;
     struct timespec ts0, ts1;
-    const double t_join = now_s();
-    gpu_warmup_join();
-    if (timing) fprintf(stderr, "[itx timing] waited %.3f s for the HIP runtime to come up\n", now_s() - t_join);
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     int ndev = itx_device_count();
     if (ndev <= 0) die("no usable MI355X (HIP) device: %s", ndev < 0 ? itx_last_error() : "none visible");
-    if (g_inflater) {
-        const aln_device_ops ops = {g_inflater,       itx_bamwin_push_begin, itx_bamwin_push_end, itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
-                                    itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    itx_bamwin_tids,  itx_bamwin_device_batch,
-                                    pool_alloc,      pool_release,     itx_last_error};
-        aln_use_device(&ops);
-    }
     /* table: every chromosome of the size file is known to the engine (a read may land on one without repeats) */
     const uint32_t n_chrom = chr_sizes->names.n;
     itx_table *tab = NULL;
@@ -253,10 +268,22 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     }
     names_t warned;
     names_init(&warned);
+    /* the helper thread (HIP start-up, device decoder, first file opened and decoding ahead) has had the rmsk parse and the
+     * table build to finish */
+    const double t_join = now_s();
+    gpu_warmup_join();
+    if (timing) fprintf(stderr, "[itx timing] waited %.3f s for the helper thread\n", now_s() - t_join);
+    if (g_inflater) use_device_reader();
     for (int fi = 0; fi < n_files; fi++) {
         if (multi_file) fprintf(stderr, "\n* Processing %s\n", files[fi]);
         const double t_open0 = now_s();
-        aln_reader *rd = aln_open(files[fi], o->is_sam);
+        aln_reader *rd = NULL;
+        if (fi == 0 && warm_reader && warm_first && strcmp(files[0], warm_first) == 0) {
+            rd = warm_reader;                                            /* opened and decoding since the helper thread came up */
+            warm_reader = NULL;
+        } else {
+            rd = aln_open(files[fi], o->is_sam);
+        }
         const double t_opened = now_s();
         if (!rd) {
             fprintf(stderr, "Fail to open %s file %s\n", o->is_sam ? "SAM" : "BAM", o->aln_arg);

@@ -95,6 +95,16 @@ struct Carver {
     }
 };
 
+#include <time.h>
+static void tb_tick(const char *what, double *t0)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double t = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    if (getenv("ITX_TIMING_TABLE")) fprintf(stderr, "[itx timing] table: %s %.3f s\n", what, t - *t0);
+    *t0 = t;
+}
+
 extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_t *chrom_size, int n_chrom,
                                 const uint32_t *rep_len, uint32_t n_rep, uint32_t n_fam, uint32_t n_cla, int device,
                                 itx_table **out, size_t *bad_row)
@@ -113,6 +123,8 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
                           (long long)chrom_size[c]);
             return ITX_E_LIMIT;
         }
+    double tb0 = 0;
+    tb_tick("start", &tb0);
     // validate rows as binKeeperAdd would, bucket by chromosome
     std::vector<uint32_t> chrom_cnt(n_chrom + 1, 0);
     std::vector<int> lvl(n_rows), bin(n_rows);
@@ -132,6 +144,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         }
         chrom_cnt[r.chrom + 1]++;
     }
+    tb_tick("validate + bucket", &tb0);
     // units: distinct (rep, fam, cla) triples, ordered by (rep, fam, cla). There are few of them (tens of thousands for
     // rmsk): collect the distinct triples through a hash, sort those, then one lookup per row.
     std::vector<uint32_t> unit_of_row(n_rows);
@@ -144,33 +157,64 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
                 return (size_t)(h ^ (h >> 29));
             }
         };
-        std::unordered_map<std::array<uint32_t, 3>, uint32_t, TripleHash> seen;
-        seen.reserve(1 << 16);
-        std::array<uint32_t, 3> last = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-        uint32_t last_id = 0;
+        // the distinct triples, found by slices of the rows in parallel and united; their ids are their ranks in sorted
+        // order, so who finds what first does not matter
+        typedef std::unordered_map<std::array<uint32_t, 3>, uint32_t, TripleHash> TripleMap;
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, n_rows / 65536 + 1}));
+        std::vector<std::vector<std::array<uint32_t, 3>>> found(n_thr);
+        auto slice = [&](size_t t, size_t &lo, size_t &hi) {
+            lo = n_rows * t / n_thr;
+            hi = n_rows * (t + 1) / n_thr;
+        };
+        {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < n_thr; t++)
+                th.emplace_back([&, t]() {
+                    size_t lo, hi;
+                    slice(t, lo, hi);
+                    TripleMap seen;
+                    seen.reserve(1 << 14);
+                    std::array<uint32_t, 3> last = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+                    for (size_t i = lo; i < hi; i++) {
+                        const std::array<uint32_t, 3> k = {rows[i].rep, rows[i].fam, rows[i].cla};
+                        if (k == last) continue;
+                        last = k;
+                        if (seen.emplace(k, 0u).second) found[t].push_back(k);
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
         std::vector<std::array<uint32_t, 3>> triples;
-        for (size_t i = 0; i < n_rows; i++) {                       // provisional ids in first-seen order
-            const std::array<uint32_t, 3> k = {rows[i].rep, rows[i].fam, rows[i].cla};
-            if (k != last) {
-                auto it = seen.find(k);
-                if (it == seen.end()) {
-                    it = seen.emplace(k, (uint32_t)triples.size()).first;
-                    triples.push_back(k);
-                }
-                last = k;
-                last_id = it->second;
-            }
-            unit_of_row[i] = last_id;
-        }
-        std::vector<uint32_t> ord(triples.size()), final_id(triples.size());
-        std::iota(ord.begin(), ord.end(), 0u);
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return triples[a] < triples[b]; });
+        for (auto &f : found) triples.insert(triples.end(), f.begin(), f.end());
+        std::sort(triples.begin(), triples.end());
+        triples.erase(std::unique(triples.begin(), triples.end()), triples.end());
+        TripleMap id_of;
+        id_of.reserve(triples.size() * 2 + 16);
         unit_ids.resize(triples.size());
-        for (size_t k = 0; k < ord.size(); k++) {
-            final_id[ord[k]] = (uint32_t)k;
-            unit_ids[k] = make_uint4(triples[ord[k]][0], triples[ord[k]][1], triples[ord[k]][2], 0);
+        for (size_t k = 0; k < triples.size(); k++) {
+            id_of.emplace(triples[k], (uint32_t)k);
+            unit_ids[k] = make_uint4(triples[k][0], triples[k][1], triples[k][2], 0);
         }
-        for (size_t i = 0; i < n_rows; i++) unit_of_row[i] = final_id[unit_of_row[i]];
+        {
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < n_thr; t++)
+                th.emplace_back([&, t]() {
+                    size_t lo, hi;
+                    slice(t, lo, hi);
+                    std::array<uint32_t, 3> last = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+                    uint32_t last_id = 0;
+                    for (size_t i = lo; i < hi; i++) {
+                        const std::array<uint32_t, 3> k = {rows[i].rep, rows[i].fam, rows[i].cla};
+                        if (k != last) {
+                            last = k;
+                            last_id = id_of.find(k)->second;
+                        }
+                        unit_of_row[i] = last_id;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
     }
     const uint32_t n_units = (uint32_t)unit_ids.size();
     std::vector<uint64_t> covoff(n_rep + 1);
@@ -199,6 +243,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
 
     std::vector<uint32_t> chrom_off(n_chrom + 1, 0);
     for (int c = 0; c < n_chrom; c++) chrom_off[c + 1] = chrom_off[c] + chrom_cnt[c + 1];
+    tb_tick("units", &tb0);
     // start-sorted order per chromosome (stable in file order)
     std::vector<uint32_t> order(n_rows);
     {
@@ -209,6 +254,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         std::stable_sort(order.begin() + chrom_off[c], order.begin() + chrom_off[c + 1],
                          [&](uint32_t a, uint32_t b) { return (int)rows[a].start < (int)rows[b].start; });
     });
+    tb_tick("sort by start", &tb0);
     // rank in binKeeperFind's return order: level coarse (5) -> fine (0), bin descending, file order ascending
     std::vector<uint32_t> rank_of_row(n_rows);
     {
@@ -224,6 +270,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
             for (uint32_t k = lo; k < hi; k++) rank_of_row[canon[k]] = k - lo;
         });
     }
+    tb_tick("ranks", &tb0);
     // bin width: about one row per bin (128 bp .. 128 kb)
     uint64_t genome = 0;
     for (int c = 0; c < n_chrom; c++) genome += (uint64_t)chrom_size[c];
@@ -274,6 +321,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         itx_set_error("itx_table_create: HIP device %d not available (%d visible)", device, ndev);
         return ITX_E_NO_DEVICE;
     }
+    tb_tick("rows + index", &tb0);
     ITX_HIP(hipSetDevice(device));
     Carver cv;
     const size_t o_iv = cv.take((n_rows + 1) * sizeof(ItxIv));
@@ -353,6 +401,7 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     memcpy(t->h_chrom_off, chrom_off.data(), sizeof(uint32_t) * (n_chrom + 1));
     memcpy(t->h_bin_off, bin_off.data(), sizeof(uint32_t) * (n_chrom + 1));
     if (n_chrom) memcpy(t->h_chrom_size, csize.data(), sizeof(int32_t) * n_chrom);
+    tb_tick("upload", &tb0);
     *out = t;
     return ITX_OK;
 }

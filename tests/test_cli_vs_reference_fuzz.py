@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import refio
-from iteres_amd import build, synth
+from iteres_amd import build, engine as eng, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -216,3 +216,41 @@ def test_long_reads_match_reference_binary(exe, tmp_path):
                 assert refio.bigwig_digest(b) == refio.bigwig_digest(a), fn
             else:
                 assert a == b, (cmd, opts, fn)
+
+
+@pytest.mark.parametrize("kind", ["header_only", "no_eof_marker", "cut_mid_block", "cut_on_block_boundary"])
+def test_odd_files_match_reference_binary(kind, exe, tmp_path):
+    """Files that end early or hold no record: the drop-in must stop where the reference stops and write the same files
+    (a truncated last block is not inflated by either; the records before it count)."""
+    chroms = [("chr1", 2_000_000)]
+    t = synth.make_table(9301, chroms, 4000, n_names=60, n_fams=10, n_clas=4)
+    r = synth.make_reads(9302, chroms, 0 if kind == "header_only" else 30_000, read_len=(30, 100))
+    inp = tmp_path / "in"
+    inp.mkdir()
+    synth.write_sizes(str(inp / "chrom.sizes"), chroms)
+    synth.write_sizes(str(inp / "rep.sizes"), t.rep_len.items())
+    synth.write_rmsk(str(inp / "rmsk.txt"), t)
+    aln = str(inp / "x.bam")
+    synth.write_bam(aln, r, with_seq=True, eof=kind not in ("no_eof_marker",), block=20_000)
+    if kind.startswith("cut"):
+        data = open(aln, "rb").read()
+        blocks = eng.index_bgzf(data)
+        k = len(blocks) * 2 // 3
+        cut = int(blocks["coff"][k]) + (int(blocks["csize"][k]) // 2 if kind == "cut_mid_block" else 0)
+        open(aln, "wb").write(data[:cut])
+    outs = {}
+    for who, prog in (("ref", REF), ("new", exe)):
+        work = tmp_path / who
+        work.mkdir()
+        pr = subprocess.run([prog, "stat", "-w", "-o", "out", str(inp / "chrom.sizes"), str(inp / "rep.sizes"), str(inp / "rmsk.txt"), aln], cwd=work,
+                            capture_output=True, text=True, timeout=600)
+        outs[who] = (pr.returncode, work, pr.stderr)
+    (rc_r, w_r, err_r), (rc_n, w_n, err_n) = outs["ref"], outs["new"]
+    assert rc_r >= 0, f"the reference itself crashed on {kind}: {err_r[-300:]}"
+    assert rc_n == rc_r, (kind, rc_n, rc_r, err_n[-800:])
+    for fn in sorted(os.listdir(w_r)):
+        a, b = (w_r / fn).read_bytes(), (w_n / fn).read_bytes()
+        if fn.endswith(".bigWig"):
+            assert refio.bigwig_digest(b) == refio.bigwig_digest(a), (kind, fn)
+        else:
+            assert a == b, (kind, fn)

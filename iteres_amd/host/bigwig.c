@@ -489,7 +489,7 @@ static void bw_tick(const char *what)
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     const double t = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-    if (getenv("ITX_TIMING_BW")) fprintf(stderr, "[bw] %s %.3f\n", what, t - bw_t0);
+    if (getenv("ITX_TIMING_BW")) fprintf(stderr, "[itx timing] bw: %s %.3f s\n", what, t - bw_t0);
     bw_t0 = t;
 }
 #define BW_T(x) bw_tick(x)

@@ -508,6 +508,8 @@ void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_si
     r->rows = xmalloc(sizeof(itx_row) * (total_rows ? total_rows : 1));
     r->row_chrom_name = xmalloc(sizeof(uint32_t) * (total_rows ? total_rows : 1));
     size_t cap_chr = 0, cap_rep = 0, cap_fam = 0, cap_cla = 0;
+    uint32_t *(*maps)[4] = xcalloc((size_t)T, sizeof *maps);
+    size_t *row_base = xcalloc((size_t)T, sizeof *row_base);
     for (int t = 0; t < T; t++) {
         rmsk_t *q = &parts[t].r;
         r->repeat_num += q->repeat_num;
@@ -572,18 +574,33 @@ void rmsk_load(const char *path, const sizes_t *chr_sizes, const sizes_t *rep_si
             r->rep_total[g] += q->rep_total[i];
             mr[i] = g;
         }
+        /* the rows themselves move afterwards, all pieces at once */
+        maps[t][0] = mc;
+        maps[t][1] = mf;
+        maps[t][2] = ml;
+        maps[t][3] = mr;
+        row_base[t] = r->n_rows;
+        r->n_rows += q->n_rows;
+    }
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; t++) {
+        rmsk_t *q = &parts[t].r;
+        const uint32_t *mc = maps[t][0], *mf = maps[t][1], *ml = maps[t][2], *mr = maps[t][3];
+        itx_row *dst = r->rows + row_base[t];
+        uint32_t *dstc = r->row_chrom_name + row_base[t];
         for (size_t i = 0; i < q->n_rows; i++) {
             itx_row row = q->rows[i];
             row.rep = mr[row.rep];
             row.fam = mf[row.fam];
             row.cla = ml[row.cla];
-            r->rows[r->n_rows] = row;
-            r->row_chrom_name[r->n_rows] = mc[q->row_chrom_name[i]];
-            r->n_rows++;
+            dst[i] = row;
+            dstc[i] = mc[q->row_chrom_name[i]];
         }
-        free(mc); free(mf); free(ml); free(mr);
+        for (int k = 0; k < 4; k++) free(maps[t][k]);
         rmsk_free(q);
     }
+    free(maps);
+    free(row_base);
     free(parts);
     free(text);
 }

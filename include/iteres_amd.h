@@ -224,7 +224,8 @@ int itx_engine_get_stats(itx_engine *e, itx_stats *out);
  * the caller's zlib has the last word, as in the reference). Synchronous; one calling thread per inflater. */
 typedef struct itx_inflater itx_inflater;
 #define ITX_BAMWIN_LANES 2        /* pushes that may be in flight at once (push_begin's s) */
-#define ITX_BAMWIN_WINDOWS 3      /* windows of inflated bytes (w): one being consumed beside the pushes in flight */
+#define ITX_BAMWIN_WINDOWS 48     /* windows of inflated bytes (w): the decode may run this far ahead of the consumer (a window's
+                                   * buffer is allocated when it is first pushed into: 288 GB of HBM is room for a long lead) */
 typedef struct itx_bgzf_block {
     uint32_t coff, csize;         /* the whole gzip member: 18-byte header, deflate data, CRC32, ISIZE */
     uint32_t uoff, usize;

@@ -46,7 +46,8 @@ struct aln_reader {
     uint8_t *cbuf;            /* compressed bytes of the current chunk (+ the incomplete block carried over):   */
     size_t clen;              /* a window into one of the two raw buffers below                                 */
     /* raw read-ahead (raw_next): a reader thread freads the next compressed chunk while this one is being inflated */
-    uint8_t *craw[ITX_BAMWIN_WINDOWS]; /* two for the host decoder; one per window for the device's (a chunk's bytes stay until its push has ended) */
+#define N_RAW_DEVICE (ITX_BAMWIN_LANES + 2)
+    uint8_t *craw[N_RAW_DEVICE]; /* two for the host decoder; for the device's: one being read, one per push in flight, one just ended */
     int n_raw;
     size_t io_got;
     int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
@@ -256,7 +257,7 @@ static size_t raw_next(aln_reader *r)
 {
     if (r->io_done) return 0;
     if (!r->io_on) {
-        r->n_raw = r->dev ? ITX_BAMWIN_WINDOWS : 2;
+        r->n_raw = r->dev ? N_RAW_DEVICE : 2;
         {
             struct stat sb;
             const int fd = fileno(r->f);
@@ -836,7 +837,7 @@ void aln_close(aln_reader *r)
         pthread_join(r->io_thread, NULL);
     }
     if (r->f) fclose(r->f);
-    for (int k = 0; k < ITX_BAMWIN_WINDOWS; k++) buf_free(r->craw[k]);
+    for (int k = 0; k < N_RAW_DEVICE; k++) buf_free(r->craw[k]);
     buf_free(r->nbuf);
     free(r->blk);
     free(r->dblk);

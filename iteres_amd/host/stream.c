@@ -34,7 +34,7 @@ static aln_reader *warm_reader;
  * its time: the helper thread gets them ready while the main thread parses the rmsk file, and hands them out from this
  * little pool. */
 static itx_inflater *g_inflater;
-#define POOL_N ITX_BAMWIN_WINDOWS
+#define POOL_N (ITX_BAMWIN_LANES + 2)
 static struct { void *p; size_t cap; int used; } pool[POOL_N];
 static pthread_mutex_t pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static void *pool_alloc(size_t n)

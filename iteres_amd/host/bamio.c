@@ -1165,6 +1165,8 @@ void aln_readahead(aln_reader *r)
     if (!r->is_sam && !r->pf_on && !r->eof) pf_start(r);
 }
 
+size_t aln_device_left(const aln_reader *r) { return r->dev ? r->dn_rec - r->drec_next : 0; }
+
 int aln_device_exhausted(aln_reader *r) { return r->dev && !dev_ensure_records(r); }
 
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b)

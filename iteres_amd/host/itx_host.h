@@ -100,6 +100,7 @@ void aln_use_device(const aln_device_ops *ops);
  * aln_read_batch_device: the next <= cap records of that window as device arrays, valid until the next reader call. */
 int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen);
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b);
+size_t aln_device_left(const aln_reader *r);  /* device decoder: records of the current window not yet taken */
 int aln_device_exhausted(aln_reader *r);
 void aln_readahead(aln_reader *r);            /* BAM: start decoding ahead of the first aln_read_batch */     /* device decoder: 1 when no record is left */
 aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the file cannot be opened / has no header */

@@ -340,7 +340,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                             ends += n;
                             tq = now_s();
                             chk(itx_engine_submit_device_own(eng, &db, n, NULL), "itx_engine_submit_device_own");
-                            chk(itx_engine_wait_own(eng), "itx_engine_wait_own");              /* the arrays are the decoder's again */
+                            /* the window's arrays are the decoder's again once its last batch is through: the next parse
+                             * overwrites them */
+                            if (aln_device_left(rd) == 0) chk(itx_engine_wait_own(eng), "itx_engine_wait_own");
                             t_submit += now_s() - tq;
                             tq = now_s();
                         } while (!aln_device_window(rd, &wfl2, &seen));                        /* until the next window's start (or the end) */

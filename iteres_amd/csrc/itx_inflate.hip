@@ -14,6 +14,13 @@
 #define ITXI_BCAST(v, j) ((uint32_t)__builtin_amdgcn_readlane((int32_t)(v), (int32_t)(j)))
 #define ITXI_AT(p, i) (p)[(i) * 64u + ln]          /* a decoder's table element i: lane-interleaved (bank = lane) */
 #define ITXI_BITREV32(x) __builtin_bitreverse32(x)
+typedef uint16_t itxi_u16x2 __attribute__((ext_vector_type(2)));
+static __device__ inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
+{
+    const itxi_u16x2 d = (__builtin_bit_cast(itxi_u16x2, a) - __builtin_bit_cast(itxi_u16x2, b)) >> (itxi_u16x2)15;     // v_pk_sub_u16, v_pk_lshrrev_b16
+    return __builtin_bit_cast(uint32_t, d);
+}
+#define ITXI_PKSIGN16(a, b) itxi_pksign16(a, b)
 #define ITXI_LOADW(w, i) ((w)[(i)])
 #define ITXI_LOADB(p, i) ((p)[(i)])
 // A far match reads bytes this wave stored earlier through other lanes. Workgroup scope is all it takes — the wave's

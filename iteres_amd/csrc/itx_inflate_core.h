@@ -28,7 +28,8 @@
 // Hooks the including file defines: ITXI_FN (function attributes), ITXI_WAVE (lanes that share pass 2: 64 / 1),
 // ITXI_UNI(x) (pass 2: a wave-uniform value as such), ITXI_AT(p, i) (pass 1: element i of a per-decoder table: lane-
 // interleaved on the device, using the lane id `ln` in scope), ITXI_BCAST(v, j) (pass 2: lane j's v, for all),
-// ITXI_BITREV32(x), ITXI_LOADW / ITXI_LOADB (global loads), ITXI_FENCE().
+// ITXI_BITREV32(x), ITXI_PKSIGN16(a, b) (bit 15 of a - b in each 16-bit half, moved to bits 0 and 16), ITXI_LOADW / ITXI_LOADB
+// (global loads), ITXI_FENCE().
 #pragma once
 #include <stdint.h>
 
@@ -64,9 +65,11 @@ struct ItxiTab {                           // one decoder's tables (element i th
 };
 
 struct ItxiCodes {
-    // lim[l - 1]: every code of length <= l, written MSB first and left-aligned to 15 bits, is below this bound (the bounds
-    // rise with l; lim[14] < 2^15 exactly when the code is incomplete)
-    uint32_t lim[15];
+    // bound l (l = 1..15): every code of length <= l, written MSB first and left-aligned to 15 bits, is below it (the bounds
+    // rise with l, up to 2^15; bound 15 < 2^15 exactly when the code is incomplete). Bounds 1..14 sit two to a word, as
+    // 16-bit halves, for packed 16-bit arithmetic; bound 15 by itself.
+    uint32_t lp[7];
+    uint32_t lim15;
 };
 
 struct ItxiIn {
@@ -122,10 +125,13 @@ ITXI_FN uint32_t itxi_decode(const ItxiCodes &h, const uint16_t *offs, uint32_t 
 {
     (void)ln;
     const uint32_t v = ITXI_BITREV32(peek) >> 17;                  // 15 bits, first stream bit on top
-    uint32_t len = 1;
+    const uint32_t vv = v | v << 16;
+    // v - bound in 16-bit halves: both are at most 2^15, so the difference's bit 15 says v < bound (also for bound = 2^15)
+    uint32_t below = 0;                                            // per half: how many bounds v has NOT reached
 #pragma unroll
-    for (int l = 0; l < 14; l++) len += v >= h.lim[l] ? 1u : 0u;
-    const bool ok = v < h.lim[14];
+    for (int k = 0; k < 7; k++) below += ITXI_PKSIGN16(vv, h.lp[k]);
+    const uint32_t len = 15u - ((below & 0xffffu) + (below >> 16));       // 1 + the number of bounds 1..14 reached
+    const bool ok = v < h.lim15;
     const uint32_t at = (uint32_t)(uint16_t)(ITXI_AT(offs, len) + (v >> (15u - len)));
     len_out = ok ? len : 0u;
     return ok ? at : 0u;                                           // a pattern that is no code must not become a table index
@@ -173,7 +179,10 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint
         ITXI_AT(offs_out, len) = (uint16_t)(index - first);
         index += cnt[len];
         first += cnt[len];
-        h.lim[len - 1] = first << (15 - len);
+        const uint32_t bound = first << (15 - len);
+        if (len == 15) h.lim15 = bound;
+        else if ((len - 1) & 1) h.lp[(len - 1) >> 1] |= bound << 16;
+        else h.lp[(len - 1) >> 1] = bound;
         first <<= 1;
     }
     return left;

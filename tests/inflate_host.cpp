@@ -16,6 +16,12 @@ static inline uint32_t itxi_bitrev32(uint32_t x)
     return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
 }
 #define ITXI_BITREV32(x) itxi_bitrev32(x)
+static inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
+{
+    const uint16_t lo = (uint16_t)((uint16_t)a - (uint16_t)b), hi = (uint16_t)((uint16_t)(a >> 16) - (uint16_t)(b >> 16));
+    return (uint32_t)(lo >> 15) | (uint32_t)(hi >> 15) << 16;
+}
+#define ITXI_PKSIGN16(a, b) itxi_pksign16(a, b)
 #define ITXI_AT(p, i) (p)[(i)]
 #define ITXI_LOADW(w, i) ((w)[i])
 #define ITXI_LOADB(p, i) ((p)[i])

@@ -118,7 +118,8 @@ def _random_opts(rng, t):
     return runs
 
 
-@pytest.mark.parametrize("seed", list(range(7100, 7148)))
+# ITX_FUZZ_EXTRA=<n>: n more seeds behind the committed 48 (a longer hunt on a GPU box)
+@pytest.mark.parametrize("seed", list(range(7100, 7148 + int(os.environ.get("ITX_FUZZ_EXTRA", "0")))))
 def test_random_case_matches_reference_binary(seed, exe, tmp_path):
     rng, chroms, t, r = _random_case(seed)
     inp = tmp_path / "in"

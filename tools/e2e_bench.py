@@ -68,7 +68,7 @@ def main():
     if ab:
         k, v = ab.split("=", 1)
         walls = {"base": [], ab: []}
-        for rep in range(3):
+        for rep in range(int(os.environ.get("ITX_E2E_AB_REPS", "3"))):
             for tag, e in (("base", env), (ab, dict(env, **{k: v}))):
                 wd = os.path.join(tmp, f"ab_{tag}_{rep}".replace("=", "_"))
                 os.makedirs(wd)

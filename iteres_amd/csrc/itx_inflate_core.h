@@ -75,6 +75,7 @@ struct ItxiCodes {
 struct ItxiIn {
     const uint32_t *w;                     // the compressed buffer as words (4-byte aligned base)
     uint32_t ip, end;                      // next word to load; byte offset of the first byte past the block's data
+    uint32_t lim;                          // end / 4 + 2: a well-formed block never loads ahead of this word (see itxi_past)
     uint64_t bb;                           // bit buffer, next bit in bit 0
     uint32_t bn;                           // valid bits in bb
     uint32_t nw;                           // word ip, loaded ahead of its use: the next load is in flight while symbols decode
@@ -90,8 +91,8 @@ ITXI_FN void itxi_in_start(ItxiIn &in, uint32_t byte_pos)
     in.nw = ITXI_LOADW(in.w, in.ip);
 }
 
-// at least 33 valid bits afterwards; reading a few words past the end is harmless (the caller pads the buffer by 16 bytes), consuming
-// them is caught by the callers through itxi_overrun
+// at least 33 valid bits afterwards; reading a few words past the end is harmless (at most 19 bytes, see itxi_past: the caller pads
+// the buffer by 16 bytes behind the block's 8-byte trailer), consuming them is caught by the callers through itxi_overrun / itxi_past
 ITXI_FN void itxi_refill(ItxiIn &in)
 {
     if (in.bn <= 32u) {
@@ -115,6 +116,13 @@ ITXI_FN bool itxi_overrun(const ItxiIn &in)                 // a bit of a byte a
     // bytes loaded so far end at 4 * ip; the last bn / 8 of them are untouched
     return in.ip * 4u - (in.bn >> 3) > in.end;
 }
+
+// The cheap bound for loops that consume input without producing a reason to stop (a run of literals): the read-ahead has
+// passed the last word a well-formed block can have loaded. A valid block has 4 * ip - bn / 8 <= end with bn <= 64 wherever
+// it is tested, so ip <= end / 4 + 2 = lim there. With the test in place every turn of the symbol loop starts at ip <= lim
+// and refills at most twice before one of the two tests ends it: the highest word ever loaded is lim + 2, i.e. at most 19
+// bytes past `end` — inside what the callers promise (a BGZF block's 8-byte trailer follows `end`, then 16 bytes of padding).
+ITXI_FN bool itxi_past(const ItxiIn &in) { return in.ip > in.lim; }
 
 // One symbol of a canonical code: codes of each length are consecutive integers, shorter codes first (RFC 1951 3.2.2), so
 // with the next 15 stream bits read MSB first as the number v, the code's length is 1 + the number of bounds v has
@@ -204,6 +212,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
     ItxiIn in;
     in.w = comp_words;
     in.end = data_end;
+    in.lim = data_end / 4u + 2u;
     itxi_in_start(in, data_pos);
     uint32_t produced = 0;                 // bytes the tokens so far stand for
     uint32_t n_lit = 0, n_tok = 0, run = 0;       // run: literals since the last match
@@ -304,6 +313,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 itxi_bits(in, cl);
                 const uint32_t sym = ITXI_AT(T.lsym, at);
                 if (sym < 256u) {
+                    if (itxi_past(in)) return ITXI_E_INPUT;       // literals out of the bytes behind the block: stop before the padding ends
                     if (produced >= usize) return ITXI_E_OUTPUT;
                     K.lit[n_lit] = (uint8_t)sym;
                     n_lit++;

@@ -12,6 +12,7 @@
 #include <omp.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 void die(const char *fmt, ...)
@@ -157,6 +158,7 @@ void names_kent_order(const names_t *t, int start_pow2, uint32_t *order)
 typedef struct {
     FILE *f;
     int is_pipe;
+    pid_t child;              /* the decompressor behind a pipe */
     char *buf;
     size_t cap;
     int line_ix;
@@ -176,17 +178,30 @@ static void lines_open(lines_t *l, const char *path)
     memset(l, 0, sizeof *l);
     l->name = path;
     if (stat(path, &sb) == 0 && S_ISDIR(sb.st_mode)) die("Error: %s is a directory not a file", path);
-    const char *prog = NULL;
-    if (ends_with(path, ".gz") || ends_with(path, ".Z")) prog = "gzip -dc";
-    else if (ends_with(path, ".bz2")) prog = "bzip2 -dc";
-    else if (ends_with(path, ".zip")) prog = "unzip -p";
+    const char *prog = NULL, *flag = NULL;
+    if (ends_with(path, ".gz") || ends_with(path, ".Z")) prog = "gzip", flag = "-dc";
+    else if (ends_with(path, ".bz2")) prog = "bzip2", flag = "-dc";
+    else if (ends_with(path, ".zip")) prog = "unzip", flag = "-p";
     if (prog) {
+        /* the decompressor is exec'd with the path as an argument of its own, like the reference's pipeline
+         * (cuskent/pipeline.c): no shell sees the file name */
         if (access(path, R_OK) != 0) die("Couldn't open %s , %s", path, strerror(errno));
-        size_t n = strlen(prog) + strlen(path) + 8;
-        char *cmd = xmalloc(n);
-        snprintf(cmd, n, "%s '%s'", prog, path);
-        l->f = popen(cmd, "r");
-        free(cmd);
+        int fd[2];
+        if (pipe(fd) != 0) die("Couldn't open %s , %s", path, strerror(errno));
+        const pid_t pid = fork();
+        if (pid < 0) die("Couldn't open %s , %s", path, strerror(errno));
+        if (pid == 0) {
+            dup2(fd[1], 1);
+            close(fd[0]);
+            close(fd[1]);
+            char *arg = xmalloc(strlen(path) + 3);          /* a name that starts with '-' must not read as an option */
+            sprintf(arg, "%s%s", path[0] == '-' ? "./" : "", path);
+            execlp(prog, prog, flag, arg, (char *)NULL);
+            _exit(127);
+        }
+        close(fd[1]);
+        l->f = fdopen(fd[0], "r");
+        l->child = pid;
         l->is_pipe = 1;
     } else {
         l->f = fopen(path, "r");
@@ -221,7 +236,11 @@ static int lines_next_words(lines_t *l, char **w, int max)
 static void lines_close(lines_t *l)
 {
     if (l->f) {
-        if (l->is_pipe) pclose(l->f); else fclose(l->f);
+        fclose(l->f);
+        if (l->is_pipe && l->child > 0) {
+            int st;
+            while (waitpid(l->child, &st, 0) < 0 && errno == EINTR) {}
+        }
     }
     free(l->buf);
     memset(l, 0, sizeof *l);

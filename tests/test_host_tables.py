@@ -60,3 +60,25 @@ def test_rmsk_parse_matches_model(case, filt, dump, tmp_path):
         assert pr.returncode == 0, pr.stderr
         got = pr.stdout.rstrip("\n").split("\n")
         assert got == want, (threads, next((a, b) for a, b in zip(got, want) if a != b))
+
+
+def test_compressed_inputs_with_awkward_names(dump, tmp_path):
+    """.gz inputs go through a decompressor that is exec'd with the path as its own argument (no shell): a name with a
+    quote, a space or a leading dash reads like any other (the reference's pipeline does the same, cuskent/pipeline.c)."""
+    import gzip
+    import shutil
+    src = os.path.join(gc.GOLDEN, "quirks", "in")
+    plain = [refio.materialise(src, n, str(tmp_path)) for n in ("chrom.sizes", "rep.sizes", "rmsk.txt")]
+    want = subprocess.run([dump] + plain, capture_output=True, text=True)
+    assert want.returncode == 0
+    odd = tmp_path / "it's a dir"
+    odd.mkdir()
+    zpaths = []
+    for p, name in zip(plain, ("chrom's.sizes.gz", "rep sizes.gz", "-rmsk.txt.gz")):
+        z = odd / name
+        with open(p, "rb") as fi, gzip.open(z, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        zpaths.append(name)
+    got = subprocess.run([dump] + zpaths, capture_output=True, text=True, cwd=str(odd))
+    assert got.returncode == 0, got.stderr
+    assert got.stdout == want.stdout

@@ -120,3 +120,64 @@ def test_damaged_streams_never_disagree_with_zlib(lib):
         assert ref is not None and ref[:len(data)] == out, trial
         agree += 1
     assert fail > 100 and agree > 10
+
+
+def _fnv(b):
+    h = 1469598103934665603
+    for x in b:
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_address_sanitizer_exact_buffers(tmp_path):
+    """The same decoder under -fsanitize=address,undefined with EXACT-size buffers (input: the block + its 8-byte trailer + the
+    16 bytes of padding the C ABI asks for; output: usize bytes). Covers what a fuzz without a sanitizer cannot see: reads
+    beyond the padding. The crafted case is the one that used to run away: a dynamic block whose 1-bit code maps the zero
+    bytes behind a truncated block to literals, usize = 65536 — it must stop with an error inside the padding."""
+    exe = str(tmp_path / "inflate_asan")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wno-unknown-pragmas", "-o", exe,
+                           os.path.join(ROOT, "tests", "inflate_asan_main.cpp"), os.path.join(ROOT, "tests", "inflate_host.cpp")])
+    rng = np.random.default_rng(11)
+    cases, expect = [], []
+    # the runaway: 'A' and end-of-block as the only two literal/length codes (1 bit each), cut short
+    aaaa = raw_deflate(b"A" * 65536, 6, zlib.Z_HUFFMAN_ONLY)
+    for cut in (len(aaaa) // 2, len(aaaa) // 4, 40, len(aaaa) - 1):
+        for at in (0, 1, 2, 3):
+            cases.append((at, aaaa[:cut], 65536))
+            expect.append(None)                              # must fail (and must not trip the sanitizer)
+    cases.append((0, aaaa, 65536))
+    expect.append(b"A" * 65536)
+    # well-formed blocks of every kind, at every alignment
+    for data in corpus(rng):
+        data = data[:65536]
+        for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_HUFFMAN_ONLY)):
+            cases.append((int(rng.integers(0, 4)), raw_deflate(data, level, strategy), len(data)))
+            expect.append(data)
+    # damaged and truncated streams: any verdict, no bad access
+    for trial in range(600):
+        data = bytes(rng.integers(0, int(rng.choice([2, 5, 64, 256])), int(rng.integers(1, 5000)), dtype=np.uint8))
+        comp = bytearray(raw_deflate(data, int(rng.choice([1, 6, 9])), int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY]))))
+        if trial % 3 == 0:
+            comp = comp[:int(rng.integers(1, len(comp) + 1))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                comp[int(rng.integers(0, len(comp)))] ^= 1 << int(rng.integers(0, 8))
+        usize = len(data) if trial % 5 else 65536
+        cases.append((int(rng.integers(0, 4)), bytes(comp), usize))
+        expect.append(False)                                 # False: don't care
+    path = tmp_path / "cases.bin"
+    with open(path, "wb") as f:
+        f.write(np.uint32(len(cases)).tobytes())
+        for at, comp, usize in cases:
+            f.write(np.array([at, len(comp), usize], np.uint32).tobytes())
+            f.write(comp)
+    pr = subprocess.run([exe, str(path)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = pr.stdout.split("\n")[:len(cases)]
+    assert len(lines) == len(cases)
+    for ln, want in zip(lines, expect):
+        rc, h = ln.split()
+        if want is None:
+            assert int(rc) != 0
+        elif want is not False:
+            assert int(rc) == 0 and int(h) == _fnv(want)

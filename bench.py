@@ -1,66 +1,296 @@
 #!/usr/bin/env python3
-"""bench.py — M alignments/s through the iteres stat hot path on MI355X.
+"""bench.py — M alignments/s through `iteres stat` (hg38 rmsk) on MI355X: the drop-in command, end to end, on files.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without WORLD_SIZE in the environment: bench.py starts `python -m torch.distributed.run` with N ranks itself,
+     as a child process, before anything touches the GPU; under torch.distributed.run it is one rank per GPU.)
 
-Workload (BASELINE.json configs[1]): a coordinate-sorted 50 M-read synthetic hg38 alignment set against a
-5.5 M-row RepeatMasker-like table (15 k names / 60 families / 20 classes), `iteres stat` defaults
-(-Q 10 -E 150 -c 1e-4), per-base coverage on. The record SoA (tid, pos, end, MAPQ, flags: 14 B/record) is
-resident in HBM when the timed region starts. One "step" = one pass of the hot path over the batch:
-classify + key emit (k_stream) -> radix partition (k_scatter) -> LDS histograms into the device accumulators (k_hist). Weak scaling: every rank owns
-its own 50 M-read shard and a replica of the table; the single end-of-stream exchange — export of the compact
-partial and one RCCL sum-reduce of it onto rank 0 (the rank that would write the files) — is INSIDE the timed region,
-after the K steps.
+Workload, N = 1 (BASELINE.json configs[2]): a coordinate-sorted 500 M-read synthetic hg38 BAM whose records carry 100 bases
++ qualities (tools/mkbam.c: BGZF level 1, ~46 B/read compressed, ~200 B/read inflated) against a 5.5 M-row
+RepeatMasker-like table (15 k names / 60 families / 20 classes), `iteres stat -w` with the reference's defaults
+(-Q 10 -E 150 -c 1e-4), per-base coverage wigs kept. One "step" = ONE whole run of the command
+(iteres_amd/host/iteres: size files + rmsk parse -> table build -> BAM decode on the device -> overlap classification +
+accumulation -> .stat/.wig/.bigWig/.report written): `value` = reads / wall time of the command — the clock the
+reference itself prints (stat.c:45,183-184). `scan_only` is the banner-to-banner scan phase (stat.c:144,153).
 
-One JSON line on rank 0. `roofline` is for the dominant kernel (k_stream: derive + classify + key emit), timed
-with HIP events recorded on the submitting stream around that launch, every step of the timed region.
-`cpu_baseline` (rank 0, N = 1): the oracle — our single-threaded C restatement of the reference loop — on a
-bounded sample of the same reads (test infrastructure used as the checker/baseline only).
+N > 1 (configs[3]): weak scaling — the command is given a file list of N copies (hard links) of that BAM, its ranks (one
+process per GPU) take equal shares of the list's compressed bytes, every rank holds a replica of the table and its own
+accumulators, and ONE sum-reduce (RCCL over xGMI) of the compact partial onto rank 0 ends the stream; rank 0 writes the
+files. `strong_scaling` in the same line: the ONE 500 M-read BAM split N ways.
+
+`roofline`: the overlap kernel k_stream (derive + classify + key emit) on the same number of records RESIDENT in HBM,
+timed with HIP events on the submitting stream around every launch; bytes counted both ways (SURVEY.md §8(d) K1 bytes
+= `achieved`/`frac`; the as-built movement = `as_built`). `cpu_baseline` (rank 0, N = 1): the REFERENCE binary
+(oracle/_ref/iteres, compiled from the reference's own sources — test infrastructure) on a bounded prefix-sized sample
+of the same workload; every text output of the two programs on that sample is compared byte for byte.
 """
 from __future__ import annotations
 
 import argparse
+import filecmp
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+OURS = os.path.join(ROOT, "iteres_amd", "host", "iteres")
+REF = os.path.join(ROOT, "oracle", "_ref", "iteres")
+MKBAM = os.path.join(ROOT, "tools", "mkbam")
+TEXT_OUTPUTS = ("out.iteres.subfamily.stat", "out.iteres.family.stat", "out.iteres.class.stat", "out.iteres.report", "out.iteres.wig",
+                "out.iteres.unique.wig")
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=500_000_000, help="reads in the BAM (configs[2]: 500 M)")
+    ap.add_argument("--seq-len", type=int, default=100, help="bases + qualities per record in the BAM (0: none)")
+    ap.add_argument("--rows", type=int, default=5_500_000)
+    ap.add_argument("--cpu-reads", type=int, default=15_000_000, help="reads of the sample the reference binary is timed on (0 = skip)")
+    ap.add_argument("--replay-steps", type=int, default=10, help="launches of the resident hot path behind `roofline` (0 = skip)")
+    ap.add_argument("--replay-reads", type=int, default=0, help="records resident for the roofline replay (0 = --reads)")
+    ap.add_argument("--threads", type=int, default=0, help="host threads of the command (0: min(16, cores))")
+    ap.add_argument("--workdir", default=os.environ.get("ITX_BENCH_DIR", ""))
+    ap.add_argument("--keep", action="store_true", help="keep the generated inputs (they are reused when present)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ inputs (rank 0)
+def ensure_inputs(a, threads):
+    """chrom.sizes / rep.sizes / rmsk.txt / reads.bam / sample.bam for these parameters, generated once per box."""
+    from iteres_amd import synth
+    key = f"r{a.reads}_s{a.seq_len}_t{a.rows}_c{a.cpu_reads}"
+    wd = a.workdir or os.path.join("/tmp", f"itx_bench_{key}")
+    os.makedirs(wd, exist_ok=True)
+    done = os.path.join(wd, "inputs.json")
+    if os.path.exists(done):
+        return wd, json.load(open(done))
+    t0 = time.time()
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", MKBAM, os.path.join(ROOT, "tools", "mkbam.c"), "-lz", "-ldl"])
+    scale = a.rows / 5_500_000
+    chroms = synth.HG38_CHROMS if scale == 1 else [(n, max(int(s * scale), 1000)) for n, s in synth.HG38_CHROMS]
+    tb = synth.make_table(20260101, chroms, a.rows, n_names=15000, n_fams=60, n_clas=20, overlap_frac=0.02)
+    synth.write_sizes(os.path.join(wd, "chrom.sizes"), chroms)
+    synth.write_sizes(os.path.join(wd, "rep.sizes"), tb.rep_len.items())
+    synth.write_rmsk(os.path.join(wd, "rmsk.txt"), tb, workers=threads)
+    t1 = time.time()
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
+    subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.reads), os.path.join(wd, "reads.bam"), str(a.seq_len), "7"], env=env)
+    if a.cpu_reads > 0:
+        subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.cpu_reads), os.path.join(wd, "sample.bam"), str(a.seq_len), "7"], env=env)
+    info = {"table_s": round(t1 - t0, 1), "bam_s": round(time.time() - t1, 1), "bam_bytes": os.path.getsize(os.path.join(wd, "reads.bam")),
+            "n_rep": len(tb.names), "n_fam": len(tb.fams), "n_cla": len(tb.clas)}
+    json.dump(info, open(done, "w"))
+    return wd, info
+
+
+def base_args(wd):
+    return ["stat", "-w", "-o", "out", os.path.join(wd, "chrom.sizes"), os.path.join(wd, "rep.sizes"), os.path.join(wd, "rmsk.txt")]
+
+
+def run_timed(exe, args, cwd, env, banners=()):
+    """Runs a command; returns (wall seconds, return code, stderr text, {banner: seconds after start when it appeared})."""
+    os.makedirs(cwd, exist_ok=True)
+    t0 = time.perf_counter()
+    p = subprocess.Popen([exe] + args, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    seen, chunks, tail = {}, [], b""
+    fd = p.stderr.fileno()
+    while True:
+        b = os.read(fd, 1 << 16)
+        if not b:
+            break
+        now = time.perf_counter() - t0
+        chunks.append(b)
+        window = tail + b
+        for s in banners:
+            if s not in seen and s.encode() in window:
+                seen[s] = now
+        tail = window[-128:]
+    rc = p.wait()
+    wall = time.perf_counter() - t0
+    return wall, rc, b"".join(chunks).decode("utf-8", "replace"), seen
+
+
+SCAN_BEGIN, SCAN_END = "* Parsing the SAM/BAM file", "* Writing stats and Wig file"
+
+
+def report_counts(path):
+    """numbers of the .report file (generic.c:53-70), in file order"""
+    out = []
+    with open(path) as f:
+        for ln in f:
+            parts = ln.replace(":", " ").replace("\t", " ").split()
+            for tok in parts[::-1]:
+                if tok.isdigit():
+                    out.append(int(tok))
+                    break
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ resident replay
+def resident_roofline(a, n_records, steps, rank, with_check):
+    """The hot path on n_records records resident in HBM (seeded on the device): HIP-event time of every k_stream launch."""
+    import numpy as np
+    import torch
+    from iteres_amd import engine as eng, synth
+    dev = torch.device("cuda", torch.cuda.current_device())
+    scale = a.rows / 5_500_000
+    chroms = synth.HG38_CHROMS if scale == 1 else [(n, max(int(s * scale), 1000)) for n, s in synth.HG38_CHROMS]
+    tb = synth.make_table(20260101, chroms, a.rows, n_names=15000, n_fams=60, n_clas=20, overlap_frac=0.02)
+    rep_len = np.array([tb.rep_len.get(n, 0) for n in tb.names], np.uint32)
+    rows = eng.make_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
+    cs = np.array([s for _, s in chroms], np.int64)
+    table = eng.Table(rows, cs, rep_len, len(tb.fams), len(tb.clas), device=dev.index)
+    e = eng.Engine(table, {}, batch_capacity=n_records)
+    e.set_tidmap(list(range(len(chroms))))
+    # the records of synth.make_reads_soa's distribution, made where they are used: uniform sorted positions over the genome,
+    # 100-150 bp, 5 % with a CIGAR that moves the end, MAPQ from the same multiset, half reverse
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260102 + rank)
+    cum = torch.tensor(np.concatenate([[0], np.cumsum(cs)]), dtype=torch.int64, device=dev)
+    gpos = torch.sort(torch.randint(0, int(cum[-1]), (n_records,), generator=g, device=dev, dtype=torch.int64)).values
+    tid64 = torch.bucketize(gpos, cum, right=True) - 1
+    pos = (gpos - cum[tid64]).to(torch.int32)
+    tid = tid64.to(torch.int32)
+    del gpos, tid64
+    rl = torch.randint(100, 151, (n_records,), generator=g, device=dev, dtype=torch.int32)
+    odd = torch.rand(n_records, generator=g, device=dev) < 0.05
+    extra = torch.where(odd, torch.randint(-4, 400, (n_records,), generator=g, device=dev, dtype=torch.int32), torch.zeros((), dtype=torch.int32, device=dev))
+    tmpend = pos + rl + extra
+    del rl, odd, extra
+    mq = torch.tensor([0, 0, 3, 20, 37, 37, 37, 60], dtype=torch.uint8, device=dev)
+    mapq = mq[torch.randint(0, 8, (n_records,), generator=g, device=dev)]
+    f5 = torch.where(torch.rand(n_records, generator=g, device=dev) < 0.5, 8, 0).to(torch.uint8)
+    d = {"tid": tid, "pos": pos, "tmpend": tmpend.contiguous(), "mapq": mapq.contiguous(), "flag5": f5.contiguous()}
+    ptrs = {k: v.data_ptr() for k, v in d.items()}
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        e.submit_device(ptrs, n_records, stream=stream)
+    e.sync()
+    e.reset()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        e.submit_device(ptrs, n_records, stream=stream)
+    e.sync()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t1
+    st = e.stats()
+    res = e.finish()
+    subs = max(st["submits"], 1)
+    stream_ms = st["stage_ms"][0] / subs
+    keys = st["keys"] / subs
+    n_rows = int(table.info.n_rows)
+    index_bytes = int(sum(s for _, s in chroms) >> int(table.info.bin_shift)) * 8
+    # 14 B in + 4 B out per read, the table (28 B x rows) and its index once per launch
+    survey_bytes = 18 * n_records + 28 * n_rows + index_bytes
+    # what the kernel moves as built: 14 B per record in, 8 B per emitted key out, 32-byte rows and the binned index once
+    built_bytes = 14 * n_records + 8 * keys + 32 * n_rows + index_bytes
+    sec = stream_ms * 1e-3
+    out = {"bound": "hbm", "kernel": "k_stream<EMIT> (derive + classify + key emit + partition count)",
+           "achieved": round(survey_bytes / sec / 1e9, 2) if sec > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(survey_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
+           "bytes_accounting": "SURVEY.md 8(d) K1: 18 B/read + 28 B x table rows + index, per launch",
+           "algorithmic_bytes_per_launch": int(survey_bytes), "avg_launch_ms": round(stream_ms, 4), "launches": int(subs),
+           "records_per_launch": n_records,
+           "as_built": {"bytes_per_launch": int(built_bytes), "achieved": round(built_bytes / sec / 1e9, 2) if sec > 0 else 0.0,
+                        "frac": round(built_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else 0.0,
+                        "what": "14 B/record in + 8 B/key out + 32 B x rows + index"},
+           "stage_ms_per_step": {k: round(v / subs, 4) for k, v in zip(("stream", None, "scatter", "hist"), st["stage_ms"]) if k},
+           "resident_hot_path_M_alignments_per_s": round(n_records * steps / wall / 1e6, 1),
+           "hits_fraction": round(int(res["cnt"][9]) / max(int(res["cnt"][0]), 1), 4)}
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        try:
+            tr = json.load(open(tj))
+            per_rec = tr.get("k_stream_bytes_per_record")
+            traffic = int(per_rec * n_records) if per_rec else tr.get("k_stream_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out["traffic"] = traffic
+    # attainable bandwidth on THIS card: a plain 1 GiB device copy, best of 5
+    src = torch.empty(1 << 28, dtype=torch.int32, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for _ in range(6):
+        ev[0].record()
+        dst.copy_(src)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms.append(ev[0].elapsed_time(ev[1]))
+    copy_gbs = 2 * src.numel() * 4 / (min(ms[1:]) * 1e-3) / 1e9
+    del src, dst
+    out["copy_kernel_GBps"] = round(copy_gbs, 1)
+    out["frac_of_copy_kernel"] = round(out["achieved"] / copy_gbs, 4)
+    checks = {"cnt0_equals_records": bool(int(res["cnt"][0]) == n_records * steps),
+              "rep_sum_equals_cnt9": bool(int(res["rep_cnt"][: len(rep_len)].sum()) == int(res["cnt"][9]))}
+    if with_check:
+        # a prefix of the same records through the oracle (the checker): the GPU path must give its numbers exactly
+        from oracle import binding as orc
+        m = min(4_000_000, n_records)
+        h = {k: v[:m].cpu().numpy() for k, v in d.items()}
+        ot = orc.OracleTable(cs, rep_len, len(tb.fams), len(tb.clas))
+        ot.add_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
+        flag16 = np.where(h["flag5"] & 8, 16, 0).astype(np.uint16)
+        want = ot.run({}, list(range(len(chroms))), h["tid"], h["pos"], h["tmpend"], h["mapq"], flag16, want_hits=False)
+        ot.close()
+        e.reset()
+        e.submit_device(ptrs, m, stream=stream)
+        got = e.finish()
+        checks["resident_sample_matches_oracle"] = bool(all(np.array_equal(got[k], want[k]) for k in ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq")))
+    e.close()
+    table.close()
+    return out, checks
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child process (nothing here has touched the GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=50_000_000)
-    ap.add_argument("--rows", type=int, default=5_500_000)
-    ap.add_argument("--accum", type=int, default=0, help="0 default (partition), 1 atomic, 2 partition")
-    ap.add_argument("--cpu-sample", type=int, default=12_000_000, help="records the CPU baseline runs over (0 = skip)")
-    ap.add_argument("--verify", type=int, default=1)
-    a = ap.parse_args()
-
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            log(f"--gpus {a.gpus} but WORLD_SIZE={world}: running with {world} ranks")
         a.gpus = world
+    threads = a.threads or max(1, min(16, len(os.sched_getaffinity(0))))
 
     import torch
     import torch.distributed as dist
     from __graft_entry__ import build
     if rank == 0:
         build()
-    # rehearsal hook for a one-GPU box (never set by the driver): every rank on cuda:0, gloo instead of RCCL — the same
-    # code path through sharding, export, exchange and the max-over-ranks clock, minus xGMI
+    # rehearsal hook for a one-GPU box (never set by the driver): every rank on cuda:0, gloo for the barriers, and the
+    # command's ranks exchange their partials through files instead of RCCL (two RCCL ranks cannot share a device)
     share_gpu = os.environ.get("ITX_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
@@ -71,29 +301,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()
-    from iteres_amd import dist as idist, engine as eng, synth
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    # ---------------------------------------------------------------- workload
-    t0 = time.time()
-    scale = a.rows / 5_500_000
-    chroms = synth.HG38_CHROMS if scale == 1 else [(n, max(int(s * scale), 1000)) for n, s in synth.HG38_CHROMS]
-    tb = synth.make_table(20260101, chroms, a.rows, n_names=15000, n_fams=60, n_clas=20, overlap_frac=0.02)
-    rep_len = np.array([tb.rep_len.get(n, 0) for n in tb.names], np.uint32)
-    rows = eng.make_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
-    cs = np.array([s for _, s in chroms], np.int64)
-    tid, pos, tmpend, mapq, f5 = synth.make_reads_soa(20260102 + rank, chroms, a.reads)
-    table = eng.Table(rows, cs, rep_len, len(tb.fams), len(tb.clas), device=local_rank)
-    e = eng.Engine(table, dict(accum=a.accum), batch_capacity=a.reads)
-    e.set_tidmap(list(range(len(chroms))))
-    d = {k: torch.from_numpy(v).to(dev) for k, v in (("tid", tid), ("pos", pos), ("tmpend", tmpend), ("mapq", mapq), ("flag5", f5))}
-    ptrs = {k: v.data_ptr() for k, v in d.items()}
-    n64, n32 = e.partial_size()
-    p64 = torch.zeros(n64, dtype=torch.int64, device=dev)      # sums are mod 2^64 / 2^32: signed containers are fine
-    p32 = torch.zeros(n32, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    setup_s = time.time() - t0
 
     def fence():
         torch.cuda.synchronize()
@@ -101,132 +310,148 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---------------------------------------------------------------- warmup, then K timed steps + the one exchange
-    for _ in range(a.warmup):
-        e.submit_device(ptrs, a.reads, stream=stream)
-    # the exchange once, untimed: the first collective of this shape pays for RCCL's channel / buffer set-up
-    e.export_partial(p64.data_ptr(), p32.data_ptr(), stream=stream)
-    idist.reduce_sum_([p64, p32], dist, dst=0)
-    e.sync()
-    e.reset()
+    # ---------------------------------------------------------------- inputs: rank 0 makes them, everybody learns where
+    box = [None, None]
+    if rank == 0:
+        t0 = time.time()
+        wd, info = ensure_inputs(a, threads)
+        info["setup_s"] = round(time.time() - t0, 1)
+        box = [wd, info]
+        log(f"inputs in {wd}: {info}")
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    wd, info = box
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), ITX_TIMING="1")
+    env.pop("ITX_RANK", None)
+    scratch = os.path.join(wd, f"run_rank{rank}")
+    shutil.rmtree(scratch, ignore_errors=True)
+    os.makedirs(scratch, exist_ok=True)
+
+    # the file list of the weak-scaling run: N hard links to the one BAM (same bytes, N x the reads)
+    bam = os.path.join(wd, "reads.bam")
+    if world > 1 and rank == 0:
+        for r in range(world):
+            ln = os.path.join(wd, f"reads_copy{r}.bam")
+            if not os.path.exists(ln):
+                os.link(bam, ln)
+    if world > 1:
+        dist.barrier()
+    weak_list = ",".join(os.path.join(wd, f"reads_copy{r}.bam") for r in range(world)) if world > 1 else bam
+
+    def one_run(aln, tag, step):
+        """one whole command over `aln` by all ranks; returns this rank's wall seconds and its stderr"""
+        e = dict(env)
+        if world > 1:
+            e.update(ITX_RANK=str(rank), ITX_WORLD=str(world), ITX_DEVICE=str(local_rank), ITX_COMM_ID=os.path.join(wd, f"comm_{tag}_{step}.id"),
+                     ITX_EXCHANGE="file" if share_gpu else "rccl")
+        wall, rc, err, seen = run_timed(OURS, base_args(wd) + [aln], scratch, e, (SCAN_BEGIN, SCAN_END))
+        if rc != 0:
+            raise RuntimeError(f"rank {rank}: iteres stat failed ({rc}): {err[-800:]}")
+        return wall, err, seen
+
+    # ---------------------------------------------------------------- warmup, then EXACTLY K timed steps
+    for w in range(a.warmup):
+        one_run(weak_list, "warm", w)
     fence()
     t1 = time.perf_counter()
-    for _ in range(a.steps):
-        e.submit_device(ptrs, a.reads, stream=stream)
-    e.export_partial(p64.data_ptr(), p32.data_ptr(), stream=stream)
-    idist.reduce_sum_([p64, p32], dist, dst=0)      # the one exchange: RCCL sum-reduce over xGMI onto the writing rank (no-op at N = 1)
+    last = None
+    for k in range(a.steps):
+        last = one_run(weak_list, "step", k)
+        if world > 1:
+            dist.barrier()
     fence()
     elapsed = time.perf_counter() - t1
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if not share_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    st = e.stats()
+    total_reads = a.reads * world * a.steps
 
-    # ---------------------------------------------------------------- results from the reduced partial (untimed)
-    res = e.finish_partial(p64.data_ptr(), p32.data_ptr())
-    total_reads = a.reads * a.steps * world
-    checks = {}
-    if a.verify:
-        checks["cnt0_equals_records"] = bool(int(res["cnt"][0]) == total_reads)
-        checks["rep_sum_equals_cnt9"] = bool(int(res["rep_cnt"][: len(rep_len)].sum()) == int(res["cnt"][9]))
-        checks["fam_sum_equals_cnt9"] = bool(int(res["fam_cnt"][: len(tb.fams)].sum()) == int(res["cnt"][9]))
-        checks["cla_uniq_sum_equals_cnt10"] = bool(int(res["cla_cnt"][len(tb.clas):].sum()) == int(res["cnt"][10]))
+    # strong scaling beside it: the ONE BAM split over the ranks (N > 1 only; two runs, the second timed)
+    strong = None
+    if world > 1:
+        one_run(bam, "strongwarm", 0)
+        fence()
+        ts = time.perf_counter()
+        one_run(bam, "strong", 0)
+        fence()
+        dt = time.perf_counter() - ts
+        tm = torch.tensor([dt], dtype=torch.float64, device=dev if not share_gpu else "cpu")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        strong = {"what": f"the one {a.reads}-read BAM split over {world} ranks (configs[3]), whole command", "wall_s": round(float(tm.item()), 3),
+                  "M_alignments_per_s": round(a.reads / float(tm.item()) / 1e6, 2)}
 
     out = None
     if rank == 0:
-        # what a plain device copy reaches on THIS card (quote the attainable figure beside the 8 TB/s
-        # spec): 1 GiB in + 1 GiB out, best of 5, after the timed region
-        src = torch.empty(1 << 28, dtype=torch.int32, device=dev).fill_(1)
-        dst = torch.empty_like(src)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        copy_ms = []
-        for _ in range(6):
-            ev[0].record()
-            dst.copy_(src)
-            ev[1].record()
-            torch.cuda.synchronize()
-            copy_ms.append(ev[0].elapsed_time(ev[1]))
-        copy_gbs = 2 * src.numel() * 4 / (min(copy_ms[1:]) * 1e-3) / 1e9
-        del src, dst
+        wall_last, err_last, seen = last
+        scan_s = seen.get(SCAN_END, 0) - seen.get(SCAN_BEGIN, 0) if SCAN_BEGIN in seen and SCAN_END in seen else None
+        phases = [ln for ln in err_last.split("\n") if ln.startswith("[itx timing]")]
+        rep = report_counts(os.path.join(scratch, "out.iteres.report"))
+        checks = {"report_total_equals_reads": bool(rep and rep[0] == a.reads * world),
+                  "outputs_written": all(os.path.exists(os.path.join(scratch, fn)) for fn in TEXT_OUTPUTS + ("out.iteres.bigWig", "out.iteres.unique.bigWig"))}
         ms_per_step = elapsed * 1e3 / a.steps
-        value = total_reads / elapsed / 1e6
-        stream_ms = st["stage_ms"][0] / max(st["submits"], 1)
-        keys = st["keys"]
-        # algorithmic bytes of one k_stream launch: 14 B per record in, 8 B per key out,
-        # plus the table rows (32 B) and binned index (8 B/bin) once per launch
-        table_once = int(table.info.n_rows) * 32 + int(sum(s for _, s in chroms) >> int(table.info.bin_shift)) * 8
-        alg_bytes = 14 * a.reads + 8 * keys + table_once
-        achieved = alg_bytes / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get("k_stream_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
-            "metric": "M alignments/sec through `iteres stat` hot path (hg38 rmsk), records resident in HBM",
-            "value": round(value, 3), "unit": "M alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 50M-read coordinate-sorted synthetic hg38 alignments vs 5.5M-row rmsk, iteres stat defaults, per-base coverage on",
-                       "reads_per_gpu_per_step": a.reads, "rmsk_rows": int(table.info.n_rows), "rep_names": len(rep_len),
-                       "consensus_slots": int(table.info.n_slots), "accumulate": "partition" if a.accum in (0, 2) else "atomic",
-                       "exchange": "1 RCCL sum-reduce of the partial onto rank 0 after the last step (inside the timed region)" if world > 1 else "partial export only (N=1)"},
-            "roofline": {"bound": "hbm", "kernel": "k_stream<EMIT> (derive + classify + key emit + partition count)",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "copy_kernel_GBps": round(copy_gbs, 1), "frac_of_copy_kernel": round(achieved / copy_gbs, 4),
-                         "avg_launch_ms": round(stream_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "stage_ms_per_step": {k: round(v / max(st["submits"], 1), 4)
-                                               for k, v in zip(("stream", None, "scatter", "hist"), st["stage_ms"]) if k}},
+            "metric": "M alignments/sec through `iteres stat` (hg38 rmsk) at 1/2/4/8 MI355X vs CPU ref",
+            "value": round(total_reads / elapsed / 1e6, 3), "unit": "M alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": (f"BASELINE configs[2]: `iteres stat -w` end to end on a {a.reads}-read coordinate-sorted synthetic hg38 BAM "
+                                    f"({a.seq_len} bases + qualities per record, {info['bam_bytes'] / 1e9:.1f} GB BGZF) vs {a.rows}-row rmsk, reference defaults, "
+                                    "per-base coverage wigs on; one step = one whole run of the command")
+                       if world == 1 else
+                       (f"BASELINE configs[3], weak: `iteres stat -w` on a list of {world} such {a.reads}-read BAMs over {world} GPUs (one process per GPU, "
+                        "shares of the compressed bytes, one RCCL sum-reduce of the partial onto rank 0, rank 0 writes the files)"),
+                       "reads_per_step": a.reads * world, "seq_len": a.seq_len, "bam_bytes": info["bam_bytes"], "rmsk_rows": a.rows,
+                       "host_threads_per_rank": threads, "host_cores_visible": os.cpu_count(),
+                       "timed_region": "K runs of the whole command (process start to exit), files in the page cache"},
+            "scan_only": {"what": "banner to banner (stat.c:144,153): device table build + BAM decode + classify + accumulate, last step",
+                          "seconds": round(scan_s, 3) if scan_s else None,
+                          "M_alignments_per_s": round(a.reads * world / scan_s / 1e6, 2) if scan_s else None},
+            "phases_last_step": phases,
             "checks": checks,
-            "hits_fraction": round(int(res["cnt"][9]) / max(total_reads, 1), 4),
-            "setup_s": round(setup_s, 1),
+            "inputs": info,
         }
+        if strong:
+            out["strong_scaling"] = strong
 
-    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
-    if rank == 0 and world == 1 and a.cpu_sample > 0:
-        from oracle import binding as orc
-        m = min(a.cpu_sample, a.reads)
-        ot = orc.OracleTable(cs, rep_len, len(tb.fams), len(tb.clas))
-        ot.add_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
-        flag16 = np.where(f5[:m] & 8, 16, 0).astype(np.uint16)
-        t2 = time.perf_counter()
-        want = ot.run({}, list(range(len(chroms))), tid[:m], pos[:m], tmpend[:m], mapq[:m], flag16, want_hits=False)
-        cpu_s = time.perf_counter() - t2
-        out["cpu_baseline"] = {"value": round(m / cpu_s / 1e6, 4), "unit": "M alignments/s", "cores": 1, "kind": "port",
-                               "sample": f"first {m} records of the same batch, oracle/liboracle.so (single-threaded C restatement of generic.c:745-1036), {cpu_s:.1f} s"}
-        # the same restatement on every host core the box gives us (the reference itself cannot do this: one thread, process
-        # globals): contiguous shards of the sample, private accumulators per thread, read-only table shared
-        nthr = max(1, min(len(os.sched_getaffinity(0)), 16))
-        if nthr > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            mm = min(a.reads, m * 4)
-            cuts = [idist.shard_bounds(mm, t, nthr) for t in range(nthr)]
-            fl_all = np.where(f5[:mm] & 8, 16, 0).astype(np.uint16)
+    # ---------------------------------------------------------------- CPU baseline: the reference binary on a bounded sample (rank 0, N = 1)
+    if rank == 0 and world == 1 and a.cpu_reads > 0 and os.path.exists(REF):
+        sample = os.path.join(wd, "sample.bam")
+        renv = dict(os.environ)
+        wall_r, rc_r, err_r, seen_r = run_timed(REF, base_args(wd) + [sample], os.path.join(wd, "ref_run"), renv, (SCAN_BEGIN, SCAN_END))
+        wall_o, rc_o, err_o, _ = run_timed(OURS, base_args(wd) + [sample], os.path.join(wd, "ours_sample"), env)
+        same = {fn: (os.path.exists(os.path.join(wd, "ours_sample", fn)) and os.path.exists(os.path.join(wd, "ref_run", fn))
+                     and filecmp.cmp(os.path.join(wd, "ref_run", fn), os.path.join(wd, "ours_sample", fn), shallow=False)) for fn in TEXT_OUTPUTS}
+        scan_r = seen_r.get(SCAN_END, 0) - seen_r.get(SCAN_BEGIN, 0) if SCAN_BEGIN in seen_r and SCAN_END in seen_r else None
+        fixed_r = wall_r - scan_r if scan_r else None
+        full_est = (fixed_r + a.reads / (a.cpu_reads / scan_r)) if scan_r else None
+        out["cpu_baseline"] = {
+            "value": round(a.cpu_reads / wall_r / 1e6, 4), "unit": "M alignments/s", "cores": 1, "kind": "reference",
+            "sample": (f"oracle/_ref/iteres stat -w (the reference's own sources, -O as its makefile, single-threaded like the reference) on a {a.cpu_reads}-read BAM "
+                       f"from the same generator / table ({wall_r:.1f} s whole command, rc {rc_r})"),
+            "scan_only_M_alignments_per_s": round(a.cpu_reads / scan_r / 1e6, 4) if scan_r else None,
+            "fixed_s": round(fixed_r, 2) if fixed_r else None,
+            "extrapolated_full_size": {"what": f"fixed_s + {a.reads} reads / scan rate (linear, BASELINE.md 3.3)", "seconds": round(full_est, 1) if full_est else None,
+                                       "M_alignments_per_s": round(a.reads / full_est / 1e6, 4) if full_est else None},
+            "drop_in_same_sample_wall_s": round(wall_o, 2),
+        }
+        out["files_identical"] = same
+        out["checks"]["sample_outputs_identical_to_reference"] = bool(rc_r == 0 and rc_o == 0 and all(same.values()))
+        if full_est:
+            out["speedup_vs_cpu_reference"] = {"whole_command_at_full_size_extrapolated": round(out["value"] / (a.reads / full_est / 1e6), 1),
+                                               "same_sample_measured": round(wall_r / wall_o, 1)}
+    elif rank == 0 and world == 1:
+        out["cpu_baseline"] = None
 
-            def one(b):
-                lo, hi = b
-                return ot.run({}, list(range(len(chroms))), tid[lo:hi], pos[lo:hi], tmpend[lo:hi], mapq[lo:hi], fl_all[lo:hi], want_hits=False)["cnt"]
-            t3 = time.perf_counter()
-            with ThreadPoolExecutor(nthr) as ex:
-                parts = list(ex.map(one, cuts))
-            mt_s = time.perf_counter() - t3
-            assert int(sum(int(c[0]) for c in parts)) == mm
-            out["cpu_baseline_mt"] = {"value": round(mm / mt_s / 1e6, 4), "unit": "M alignments/s", "cores": nthr, "kind": "port",
-                                      "sample": f"first {mm} records in {nthr} contiguous shards, one oracle thread each (private accumulators, merge not timed), {mt_s:.1f} s"}
-        if a.verify:
-            # the same sample through the GPU path must give the oracle's numbers exactly
-            e.reset()
-            e.submit_device(ptrs, m, stream=stream)
-            got = e.finish()
-            out["checks"]["sample_matches_oracle"] = bool(all(np.array_equal(got[k], want[k]) for k in ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq")))
-        ot.close()
+    # ---------------------------------------------------------------- roofline of the overlap kernel, records resident in HBM (rank 0)
+    if rank == 0 and a.replay_steps > 0:
+        n_res = a.replay_reads or a.reads
+        roof, rchecks = resident_roofline(a, n_res, a.replay_steps, rank, with_check=(world == 1))
+        out["roofline"] = roof
+        out["checks"].update(rchecks)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    e.close()
-    table.close()
+        if not a.keep:
+            shutil.rmtree(scratch, ignore_errors=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -129,20 +129,47 @@ def write_sizes(path, pairs):
             f.write(f"{n}\t{s}\n")
 
 
-def write_rmsk(path, t: Table, extra_rows=()):
+def _rmsk_lines(t: Table, lo: int, hi: int) -> str:
+    out = []
+    for i in range(lo, hi):
+        nm = t.names[t.rep_name[i]]
+        L = t.rep_len.get(nm, 0)
+        cs, ce = int(t.cons_start[i]), int(t.cons_end[i])
+        left = -(max(L - ce, 0))
+        c13, c15 = (cs, left) if t.strand[i] == ord("+") else (left, cs)
+        cname, csize = t.chroms[t.chrom[i]]
+        out.append(f"{585 + (int(t.start[i]) >> 17)}\t{1000 + i % 977}\t{i % 300}\t{i % 40}\t{i % 30}\t{cname}\t"
+                   f"{int(t.start[i])}\t{int(t.end[i])}\t{-(csize - int(t.end[i]))}\t{chr(t.strand[i])}\t{nm}\t"
+                   f"{t.clas[t.cla_of_row[i]]}\t{t.fams[t.fam_of_row[i]]}\t{c13}\t{ce}\t{c15}\t{i % 9 + 1}\n")
+    return "".join(out)
+
+
+_RMSK_JOB = None
+
+
+def _rmsk_chunk(b):
+    return _rmsk_lines(_RMSK_JOB, b[0], b[1])
+
+
+def write_rmsk(path, t: Table, extra_rows=(), workers: int = 1):
     """17 UCSC columns: bin swScore milliDiv milliDel milliIns genoName genoStart genoEnd genoLeft
-    strand repName repClass repFamily repStart repEnd repLeft id."""
+    strand repName repClass repFamily repStart repEnd repLeft id. workers > 1: pieces of the table are formatted by
+    forked helper processes (the text is the same)."""
+    global _RMSK_JOB
+    n = len(t.start)
     with open(path, "w") as f:
-        for i in range(len(t.start)):
-            nm = t.names[t.rep_name[i]]
-            L = t.rep_len.get(nm, 0)
-            cs, ce = int(t.cons_start[i]), int(t.cons_end[i])
-            left = -(max(L - ce, 0))
-            c13, c15 = (cs, left) if t.strand[i] == ord("+") else (left, cs)
-            cname, csize = t.chroms[t.chrom[i]]
-            f.write(f"{585 + (int(t.start[i]) >> 17)}\t{1000 + i % 977}\t{i % 300}\t{i % 40}\t{i % 30}\t{cname}\t"
-                    f"{int(t.start[i])}\t{int(t.end[i])}\t{-(csize - int(t.end[i]))}\t{chr(t.strand[i])}\t{nm}\t"
-                    f"{t.clas[t.cla_of_row[i]]}\t{t.fams[t.fam_of_row[i]]}\t{c13}\t{ce}\t{c15}\t{i % 9 + 1}\n")
+        if workers > 1 and n > 200_000:
+            import multiprocessing as mp
+            step = 100_000
+            _RMSK_JOB = t
+            try:
+                with mp.get_context("fork").Pool(workers) as pool:
+                    for txt in pool.imap(_rmsk_chunk, [(a, min(a + step, n)) for a in range(0, n, step)]):
+                        f.write(txt)
+            finally:
+                _RMSK_JOB = None
+        else:
+            f.write(_rmsk_lines(t, 0, n))
         for row in extra_rows:
             f.write("\t".join(str(x) for x in row) + "\n")
 

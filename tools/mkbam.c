@@ -1,21 +1,27 @@
 /* mkbam.c — fast generator of a synthetic coordinate-sorted BAM for end-to-end throughput runs (test tool).
  *
- *   mkbam <chrom.sizes> <n_reads> <out.bam> [seq_len=0] [seed=1]
+ *   mkbam <chrom.sizes> <n_reads> <out.bam> [seq_len=0] [seed=1] [xa_permille=0]
  *
- * Single-end reads, uniform positions (exponential gaps), 50 % reverse strand, MAPQ from {0,0,3,20,37,37,37,60},
- * read length 100-150, CIGAR nM; with seq_len > 0 every record carries that many bases + qualities (what real
- * BAMs look like: ~5x more bytes to inflate per record). BGZF blocks are compressed in parallel (OpenMP, level 1). */
+ * Single-end reads, positions increasing along every chromosome (one read per mean gap, jittered), 50 % reverse strand,
+ * MAPQ from {0,0,3,20,37,37,37,60}, read length 100-150, CIGAR nM; with seq_len > 0 every record carries that many bases
+ * (4-bit codes of A/C/G/T) + qualities — what real BAMs look like: ~5x more bytes to inflate per record. xa_permille: that
+ * many reads per thousand carry `XA:Z:<chrom>,<+-pos>,<len>M,<nm>;...` (1-3 alternatives anywhere in the genome) and NM:i.
+ *
+ * The file is a function of the arguments alone: reads are generated in segments of SEG reads, each from a generator seeded
+ * by (seed, segment number), each compressed into its own run of BGZF blocks (level 1; libdeflate when the system has it,
+ * zlib otherwise — MKBAM_ZLIB=1 forces zlib), by as many threads as OpenMP gives; segments are written in order. */
 #define _GNU_SOURCE
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
-static uint64_t rng_state;
-static inline uint64_t rnd(void)
+typedef struct { uint64_t s; } rng_t;
+static inline uint64_t rnd(rng_t *g)
 {
-    uint64_t z = (rng_state += 0x9e3779b97f4a7c15ull);
+    uint64_t z = (g->s += 0x9e3779b97f4a7c15ull);
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
@@ -25,16 +31,21 @@ typedef struct {
     uint8_t *p;
     size_t n, cap;
 } buf_t;
-static void put(buf_t *b, const void *src, size_t k)
+static inline void need(buf_t *b, size_t k)
 {
     if (b->n + k > b->cap) {
         b->cap = (b->n + k) * 2 + 4096;
         b->p = realloc(b->p, b->cap);
+        if (!b->p) abort();
     }
+}
+static inline void put(buf_t *b, const void *src, size_t k)
+{
+    need(b, k);
     memcpy(b->p + b->n, src, k);
     b->n += k;
 }
-static void put32(buf_t *b, uint32_t v) { put(b, &v, 4); }
+static inline void put32(buf_t *b, uint32_t v) { put(b, &v, 4); }
 
 static int reg2bin(int beg, int end)
 {
@@ -47,20 +58,43 @@ static int reg2bin(int beg, int end)
     return 0;
 }
 
+/* ---- raw DEFLATE of one block, level 1 */
+typedef struct libdeflate_compressor ld_comp;
+static ld_comp *(*ld_alloc)(int);
+static size_t (*ld_compress)(ld_comp *, const void *, size_t, void *, size_t);
+static int use_ld;
+static void ld_probe(void)
+{
+    if (getenv("MKBAM_ZLIB")) return;
+    void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    ld_alloc = (ld_comp * (*)(int)) dlsym(h, "libdeflate_alloc_compressor");
+    ld_compress = (size_t(*)(ld_comp *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+    use_ld = ld_alloc && ld_compress;
+}
+
 #define BLK 0xff00
 static size_t bgzf_compress(const uint8_t *src, size_t n, uint8_t *dst)
 {
     static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-    zs.next_in = (Bytef *)src;
-    zs.avail_in = (uInt)n;
-    zs.next_out = dst + 18;
-    zs.avail_out = 0x10000;
-    deflate(&zs, Z_FINISH);
-    const size_t clen = zs.total_out;
-    deflateEnd(&zs);
+    size_t clen = 0;
+    if (use_ld) {
+        static __thread ld_comp *c;
+        if (!c) c = ld_alloc(1);
+        clen = c ? ld_compress(c, src, n, dst + 18, 0x10000) : 0;
+    }
+    if (!clen) {
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = (Bytef *)src;
+        zs.avail_in = (uInt)n;
+        zs.next_out = dst + 18;
+        zs.avail_out = 0x10000;
+        deflate(&zs, Z_FINISH);
+        clen = zs.total_out;
+        deflateEnd(&zs);
+    }
     memcpy(dst, hdr, 16);
     const uint16_t bsize = (uint16_t)(clen + 25);
     memcpy(dst + 16, &bsize, 2);
@@ -70,101 +104,199 @@ static size_t bgzf_compress(const uint8_t *src, size_t n, uint8_t *dst)
     return clen + 26;
 }
 
-static void flush_blocks(FILE *f, buf_t *b, int final)
+/* the inflated bytes of `b` as BGZF blocks of BLK bytes (the last one shorter) appended to `out` */
+static void compress_all(const buf_t *b, buf_t *out)
 {
-    const size_t nb = final ? (b->n + BLK - 1) / BLK : b->n / BLK;
-    if (!nb) return;
-    uint8_t *out = malloc(nb * 0x10100);
-    size_t *len = malloc(nb * sizeof *len);
-#pragma omp parallel for schedule(dynamic, 8)
-    for (long i = 0; i < (long)nb; i++) {
-        const size_t off = (size_t)i * BLK, k = b->n - off < BLK ? b->n - off : BLK;
-        len[i] = bgzf_compress(b->p + off, k, out + (size_t)i * 0x10100);
+    for (size_t off = 0; off < b->n; off += BLK) {
+        const size_t k = b->n - off < BLK ? b->n - off : BLK;
+        need(out, 0x10100);
+        out->n += bgzf_compress(b->p + off, k, out->p + out->n);
     }
-    for (size_t i = 0; i < nb; i++) fwrite(out + i * 0x10100, 1, len[i], f);
-    const size_t used = nb * BLK < b->n ? nb * BLK : b->n;
-    memmove(b->p, b->p + used, b->n - used);
-    b->n -= used;
-    free(out);
-    free(len);
 }
+
+static inline int put_dec(char *dst, long long v)          /* decimal digits, returns their number */
+{
+    char tmp[24];
+    int k = 0;
+    do {
+        tmp[k++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    for (int i = 0; i < k; i++) dst[i] = tmp[k - 1 - i];
+    return k;
+}
+
+#define SEG 65536
+typedef struct {
+    int chrom;
+    long long first, count, serial;      /* reads [first, first + count) of the chromosome; serial = number of the first among all reads */
+} seg_t;
 
 int main(int argc, char **argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "usage: mkbam <chrom.sizes> <n_reads> <out.bam> [seq_len=0] [seed=1]\n");
+        fprintf(stderr, "usage: mkbam <chrom.sizes> <n_reads> <out.bam> [seq_len=0] [seed=1] [xa_permille=0]\n");
         return 1;
     }
     const long long n_reads = atoll(argv[2]);
     const int seq_len = argc > 4 ? atoi(argv[4]) : 0;
-    rng_state = argc > 5 ? strtoull(argv[5], 0, 0) : 1;
-    char names[256][64];
-    long long sizes[256];
+    const uint64_t seed = argc > 5 ? strtoull(argv[5], 0, 0) : 1;
+    const unsigned xa_pm = argc > 6 ? (unsigned)atoi(argv[6]) : 0;
+    static char names[256][64];
+    static long long sizes[256], nr_of[256];
     int nc = 0;
     FILE *cf = fopen(argv[1], "r");
     if (!cf) return 2;
     while (nc < 256 && fscanf(cf, "%63s %lld", names[nc], &sizes[nc]) == 2) nc++;
     fclose(cf);
+    if (nc == 0) return 2;
     long long genome = 0;
     for (int c = 0; c < nc; c++) genome += sizes[c];
     FILE *f = fopen(argv[3], "wb");
     if (!f) return 3;
-    buf_t b = {0};
-    char text[16384];
-    int tl = snprintf(text, sizeof text, "@HD\tVN:1.0\tSO:coordinate\n");
-    for (int c = 0; c < nc; c++) tl += snprintf(text + tl, sizeof text - tl, "@SQ\tSN:%s\tLN:%lld\n", names[c], sizes[c]);
-    put(&b, "BAM\1", 4);
-    put32(&b, (uint32_t)tl);
-    put(&b, text, (size_t)tl);
-    put32(&b, (uint32_t)nc);
+    ld_probe();
+
+    /* header: its own blocks */
+    {
+        buf_t b = {0}, o = {0};
+        char *text = malloc(64 + (size_t)nc * 128);
+        int tl = sprintf(text, "@HD\tVN:1.0\tSO:coordinate\n");
+        for (int c = 0; c < nc; c++) tl += sprintf(text + tl, "@SQ\tSN:%s\tLN:%lld\n", names[c], sizes[c]);
+        put(&b, "BAM\1", 4);
+        put32(&b, (uint32_t)tl);
+        put(&b, text, (size_t)tl);
+        put32(&b, (uint32_t)nc);
+        for (int c = 0; c < nc; c++) {
+            const uint32_t l = (uint32_t)strlen(names[c]) + 1;
+            put32(&b, l);
+            put(&b, names[c], l);
+            put32(&b, (uint32_t)sizes[c]);
+        }
+        compress_all(&b, &o);
+        fwrite(o.p, 1, o.n, f);
+        free(b.p);
+        free(o.p);
+        free(text);
+    }
+
+    /* the segments */
+    long long done = 0, n_seg = 0;
     for (int c = 0; c < nc; c++) {
-        const uint32_t l = (uint32_t)strlen(names[c]) + 1;
-        put32(&b, l);
-        put(&b, names[c], l);
-        put32(&b, (uint32_t)sizes[c]);
+        nr_of[c] = c == nc - 1 ? n_reads - done : (long long)((double)n_reads * (double)sizes[c] / (double)genome);
+        if (nr_of[c] < 0) nr_of[c] = 0;
+        done += nr_of[c];
+        n_seg += (nr_of[c] + SEG - 1) / SEG;
+    }
+    seg_t *seg = malloc(sizeof *seg * (size_t)(n_seg + 1));
+    {
+        long long k = 0, serial = 0;
+        for (int c = 0; c < nc; c++)
+            for (long long a = 0; a < nr_of[c]; a += SEG) {
+                seg[k].chrom = c;
+                seg[k].first = a;
+                seg[k].count = nr_of[c] - a < SEG ? nr_of[c] - a : SEG;
+                seg[k].serial = serial;
+                serial += seg[k].count;
+                k++;
+            }
     }
     static const uint8_t mq[8] = {0, 0, 3, 20, 37, 37, 37, 60};
-    uint8_t *seq = calloc((size_t)seq_len + 8, 2);
-    long long done = 0;
-    for (int c = 0; c < nc; c++) {
-        const long long nr = c == nc - 1 ? n_reads - done : (long long)((double)n_reads * sizes[c] / genome);
-        const double mean_gap = (double)sizes[c] / (double)(nr + 1);
-        double p = 0;
-        for (long long i = 0; i < nr; i++) {
-            const uint64_t r = rnd();
-            p += mean_gap * (0.25 + 1.5 * (double)(r >> 40) / (double)(1 << 24));       /* increasing, mean = mean_gap */
-            int pos = (int)p;
-            if (pos >= sizes[c]) pos = (int)sizes[c] - 1;
-            const int rl = 100 + (int)((r >> 8) % 51);
-            const int flag = (r & 1) ? 16 : 0;
-            char qn[32];
-            const int ql = snprintf(qn, sizeof qn, "r%lld", done + i) + 1;
-            const int l_seq = seq_len;
-            const uint32_t block = 32 + (uint32_t)ql + 4 + (uint32_t)((l_seq + 1) / 2 + l_seq);
-            put32(&b, block);
-            put32(&b, (uint32_t)c);
-            put32(&b, (uint32_t)pos);
-            put32(&b, ((uint32_t)reg2bin(pos, pos + rl) << 16) | ((uint32_t)mq[(r >> 4) & 7] << 8) | (uint32_t)ql);
-            put32(&b, ((uint32_t)flag << 16) | 1u);
-            put32(&b, (uint32_t)l_seq);
-            put32(&b, 0xffffffffu);
-            put32(&b, 0xffffffffu);
-            put32(&b, 0);
-            put(&b, qn, (size_t)ql);
-            put32(&b, ((uint32_t)rl << 4) | 0u);
-            if (l_seq) {
-                for (int k = 0; k < (l_seq + 1) / 2; k++) seq[k] = (uint8_t)(0x11 << ((rnd() >> 13) & 3));
-                for (int k = 0; k < l_seq; k++) seq[(l_seq + 1) / 2 + k] = (uint8_t)(20 + ((r >> (k & 31)) & 15));
-                put(&b, seq, (size_t)((l_seq + 1) / 2 + l_seq));
+    static const uint8_t base2[4] = {0x11, 0x22, 0x44, 0x88};
+    int io_error = 0;
+#pragma omp parallel
+    {
+        buf_t b = {0}, o = {0};
+        uint8_t *sq = malloc((size_t)seq_len * 2 + 64);
+#pragma omp for ordered schedule(dynamic, 1)
+        for (long long s = 0; s < n_seg; s++) {
+            const seg_t *g = &seg[s];
+            rng_t R = {seed * 0x2545f4914f6cdd1dull + (uint64_t)s * 0x9e3779b97f4a7c15ull + 1};
+            const int c = g->chrom;
+            const double mean_gap = (double)sizes[c] / (double)(nr_of[c] + 1);
+            b.n = 0;
+            o.n = 0;
+            for (long long i = 0; i < g->count; i++) {
+                const uint64_t r = rnd(&R);
+                /* read k of the chromosome sits in [k, k + 1) mean gaps: increasing in k without any running state */
+                int pos = (int)(((double)(g->first + i) + (double)(r >> 40) / (double)(1 << 24)) * mean_gap);
+                if (pos >= sizes[c]) pos = (int)sizes[c] - 1;
+                const int rl = 100 + (int)((r >> 8) % 51);
+                const int flag = (r & 1) ? 16 : 0;
+                char qn[32];
+                qn[0] = 'r';
+                int ql = 1 + put_dec(qn + 1, g->serial + i);
+                qn[ql++] = 0;
+                const int l_seq = seq_len;
+                char xa[256];
+                int xl = 0;
+                if (xa_pm && (unsigned)((r >> 20) % 1000) < xa_pm) {
+                    const uint64_t x = rnd(&R);
+                    const int n_alt = 1 + (int)(x % 3);
+                    xa[xl++] = 'X', xa[xl++] = 'A', xa[xl++] = 'Z';
+                    for (int a = 0; a < n_alt; a++) {
+                        const uint64_t y = rnd(&R);
+                        const int ac = (int)(y % (uint64_t)nc);
+                        const long long ap = 1 + (long long)((y >> 16) % (uint64_t)(sizes[ac] > rl ? sizes[ac] - rl : 1));
+                        xl += sprintf(xa + xl, "%s,%c", names[ac], (y >> 8) & 1 ? '-' : '+');
+                        xl += put_dec(xa + xl, ap);
+                        xl += sprintf(xa + xl, ",%dM,%d;", rl, (int)((y >> 9) & 3));
+                    }
+                    xa[xl++] = 0;
+                    xa[xl++] = 'N', xa[xl++] = 'M', xa[xl++] = 'C', xa[xl++] = (char)((x >> 8) & 3);
+                }
+                const uint32_t block = 32 + (uint32_t)ql + 4 + (uint32_t)((l_seq + 1) / 2 + l_seq) + (uint32_t)xl;
+                need(&b, block + 4);
+                uint32_t *w = (uint32_t *)(void *)(b.p + b.n);          /* unaligned stores are fine on the hosts this runs on */
+                uint32_t hdr[9] = {block,
+                                   (uint32_t)c,
+                                   (uint32_t)pos,
+                                   ((uint32_t)reg2bin(pos, pos + rl) << 16) | ((uint32_t)mq[(r >> 4) & 7] << 8) | (uint32_t)ql,
+                                   ((uint32_t)flag << 16) | 1u,
+                                   (uint32_t)l_seq,
+                                   0xffffffffu,
+                                   0xffffffffu,
+                                   0};
+                memcpy(w, hdr, 36);
+                b.n += 36;
+                memcpy(b.p + b.n, qn, (size_t)ql);
+                b.n += (size_t)ql;
+                const uint32_t cg = ((uint32_t)rl << 4) | 0u;
+                memcpy(b.p + b.n, &cg, 4);
+                b.n += 4;
+                if (l_seq) {
+                    const int nb = (l_seq + 1) / 2;
+                    for (int k = 0; k < nb; k += 32) {                /* 2 random bits per byte: both nibbles the same base code */
+                        uint64_t y = rnd(&R);
+                        for (int j = 0; j < 32; j++, y >>= 2) sq[k + j] = base2[y & 3];
+                    }
+                    uint8_t *q = sq + nb + 32;
+                    for (int k = 0; k < l_seq; k++) q[k] = (uint8_t)(20 + ((r >> (k & 31)) & 15));
+                    memcpy(b.p + b.n, sq, (size_t)nb);
+                    memcpy(b.p + b.n + nb, q, (size_t)l_seq);
+                    b.n += (size_t)(nb + l_seq);
+                }
+                if (xl) {
+                    memcpy(b.p + b.n, xa, (size_t)xl);
+                    b.n += (size_t)xl;
+                }
             }
-            if (b.n >= (size_t)BLK * 4096) flush_blocks(f, &b, 0);
+            compress_all(&b, &o);
+#pragma omp ordered
+            {
+                if (fwrite(o.p, 1, o.n, f) != o.n) io_error = 1;
+            }
         }
-        done += nr;
+        free(b.p);
+        free(o.p);
+        free(sq);
     }
-    flush_blocks(f, &b, 1);
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     fwrite(eof, 1, 28, f);
-    fclose(f);
-    fprintf(stderr, "wrote %lld records\n", done);
+    if (fclose(f) != 0 || io_error) {
+        fprintf(stderr, "mkbam: write error\n");
+        return 4;
+    }
+    free(seg);
+    fprintf(stderr, "wrote %lld records (%s level 1)\n", done, use_ld ? "libdeflate" : "zlib");
     return 0;
 }

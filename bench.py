@@ -157,25 +157,7 @@ def resident_roofline(a, n_records, steps, rank, with_check):
     table = eng.Table(rows, cs, rep_len, len(tb.fams), len(tb.clas), device=dev.index)
     e = eng.Engine(table, {}, batch_capacity=n_records)
     e.set_tidmap(list(range(len(chroms))))
-    # the records of synth.make_reads_soa's distribution, made where they are used: uniform sorted positions over the genome,
-    # 100-150 bp, 5 % with a CIGAR that moves the end, MAPQ from the same multiset, half reverse
-    g = torch.Generator(device=dev)
-    g.manual_seed(20260102 + rank)
-    cum = torch.tensor(np.concatenate([[0], np.cumsum(cs)]), dtype=torch.int64, device=dev)
-    gpos = torch.sort(torch.randint(0, int(cum[-1]), (n_records,), generator=g, device=dev, dtype=torch.int64)).values
-    tid64 = torch.bucketize(gpos, cum, right=True) - 1
-    pos = (gpos - cum[tid64]).to(torch.int32)
-    tid = tid64.to(torch.int32)
-    del gpos, tid64
-    rl = torch.randint(100, 151, (n_records,), generator=g, device=dev, dtype=torch.int32)
-    odd = torch.rand(n_records, generator=g, device=dev) < 0.05
-    extra = torch.where(odd, torch.randint(-4, 400, (n_records,), generator=g, device=dev, dtype=torch.int32), torch.zeros((), dtype=torch.int32, device=dev))
-    tmpend = pos + rl + extra
-    del rl, odd, extra
-    mq = torch.tensor([0, 0, 3, 20, 37, 37, 37, 60], dtype=torch.uint8, device=dev)
-    mapq = mq[torch.randint(0, 8, (n_records,), generator=g, device=dev)]
-    f5 = torch.where(torch.rand(n_records, generator=g, device=dev) < 0.5, 8, 0).to(torch.uint8)
-    d = {"tid": tid, "pos": pos, "tmpend": tmpend.contiguous(), "mapq": mapq.contiguous(), "flag5": f5.contiguous()}
+    d = synth.make_reads_device(20260102 + rank, chroms, n_records, dev)      # the records, made in HBM
     ptrs = {k: v.data_ptr() for k, v in d.items()}
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(2):

@@ -404,3 +404,29 @@ def make_reads_soa(seed: int, header, n: int, read_len=(100, 150), odd_cigar_fra
     mapq = rng.choice(np.array([0, 0, 3, 20, 37, 37, 37, 60], np.uint8), n)
     flag5 = np.where(rng.random(n) < 0.5, 8, 0).astype(np.uint8)      # bit3 = reverse strand
     return tid, pos, tmpend, mapq, flag5
+
+
+def make_reads_device(seed: int, header, n: int, device):
+    """make_reads_soa's distribution made where it is used — in HBM, with torch's device generator (bench.py's resident
+    replay and the BASELINE-size GPU tests: 500 M records are 7 GB): uniform sorted positions over the genome, 100-150 bp,
+    5 % with a CIGAR that moves the end, MAPQ from the same multiset, half reverse. Returns a dict of contiguous device
+    tensors tid/pos/tmpend (int32) and mapq/flag5 (uint8). Not the same draws as the numpy generator."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sizes = np.array([s for _, s in header], dtype=np.int64)
+    cum = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64, device=device)
+    gpos = torch.sort(torch.randint(0, int(cum[-1]), (n,), generator=g, device=device, dtype=torch.int64)).values
+    tid64 = torch.bucketize(gpos, cum, right=True) - 1
+    pos = (gpos - cum[tid64]).to(torch.int32)
+    tid = tid64.to(torch.int32)
+    del gpos, tid64
+    rl = torch.randint(100, 151, (n,), generator=g, device=device, dtype=torch.int32)
+    odd = torch.rand(n, generator=g, device=device) < 0.05
+    extra = torch.where(odd, torch.randint(-4, 400, (n,), generator=g, device=device, dtype=torch.int32), torch.zeros((), dtype=torch.int32, device=device))
+    tmpend = (pos + rl + extra).contiguous()
+    del rl, odd, extra
+    mq = torch.tensor([0, 0, 3, 20, 37, 37, 37, 60], dtype=torch.uint8, device=device)
+    mapq = mq[torch.randint(0, 8, (n,), generator=g, device=device)].contiguous()
+    f5 = torch.where(torch.rand(n, generator=g, device=device) < 0.5, 8, 0).to(torch.uint8).contiguous()
+    return {"tid": tid.contiguous(), "pos": pos.contiguous(), "tmpend": tmpend, "mapq": mapq, "flag5": f5}

@@ -303,7 +303,7 @@ def main():
     if world > 1:
         dist.broadcast_object_list(box, src=0)
     wd, info = box
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), ITX_TIMING="1")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), ITX_TIMING="1", ITX_GPUS="1")      # --gpus decides, not the node: the ranks are this launcher's
     env.pop("ITX_RANK", None)
     scratch = os.path.join(wd, f"run_rank{rank}")
     shutil.rmtree(scratch, ignore_errors=True)
@@ -343,6 +343,7 @@ def main():
             dist.barrier()
     fence()
     elapsed = time.perf_counter() - t1
+    rep = report_counts(os.path.join(scratch, "out.iteres.report")) if rank == 0 else []
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if not share_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -368,7 +369,6 @@ def main():
         wall_last, err_last, seen = last
         scan_s = seen.get(SCAN_END, 0) - seen.get(SCAN_BEGIN, 0) if SCAN_BEGIN in seen and SCAN_END in seen else None
         phases = [ln for ln in err_last.split("\n") if ln.startswith("[itx timing]")]
-        rep = report_counts(os.path.join(scratch, "out.iteres.report"))
         checks = {"report_total_equals_reads": bool(rep and rep[0] == a.reads * world),
                   "outputs_written": all(os.path.exists(os.path.join(scratch, fn)) for fn in TEXT_OUTPUTS + ("out.iteres.bigWig", "out.iteres.unique.bigWig"))}
         ms_per_step = elapsed * 1e3 / a.steps

@@ -200,6 +200,26 @@ int itx_engine_finish(itx_engine *e, const itx_result *out);
 int itx_engine_partial_size(const itx_engine *e, uint64_t *n_u64, uint64_t *n_u32);
 int itx_engine_export_partial(itx_engine *e, void *d_u64, void *d_u32, void *stream);
 int itx_engine_finish_partial(itx_engine *e, const void *d_u64, const void *d_u32, const itx_result *out);
+/* The engine's own pair of partial buffers (device memory of the sizes above, owned by the engine): for a caller without
+ * a device allocator of its own — export into them, reduce them across ranks (itx_comm_reduce_sum), finish from them. */
+int itx_engine_partial_buffers(itx_engine *e, void **d_u64, void **d_u32);
+
+/* The exchange itself, for a host that runs one process per GPU (iteres_amd/host: `iteres stat|filter` with ITX_GPUS /
+ * ITX_RANK + ITX_WORLD): replaces nothing in the reference, which has one thread and one set of counters
+ * (generic.c:705-722) — it is what makes N replicas of that loop one job. itx_comm_create: rank 0 publishes the
+ * communicator id as the file `id_path`, the others wait for it. itx_comm_reduce_sum: sum over ranks of the two device
+ * buffers of a partial (and of a small host vector `meta`, n_meta <= 64: the host's own counters) onto rank 0, in place,
+ * behind `stream`'s work; returns when the result is there (other ranks: when their part is handed over).
+ *   ITX_COMM_RCCL  ncclReduce over xGMI (librccl is loaded on first use)
+ *   ITX_COMM_FILE  through files next to id_path, added on the host — for ranks that share a device (rehearsals on a
+ *                  one-GPU box: RCCL refuses two ranks on one GPU)
+ * Waiting is bounded (ITX_COMM_TIMEOUT seconds, default 900). */
+typedef struct itx_comm itx_comm;
+#define ITX_COMM_RCCL 0
+#define ITX_COMM_FILE 1
+int itx_comm_create(int rank, int world, int device, const char *id_path, int mode, itx_comm **out);
+void itx_comm_destroy(itx_comm *c);
+int itx_comm_reduce_sum(itx_comm *c, void *d_u64, size_t n64, void *d_u32, size_t n32, uint64_t *meta, size_t n_meta, void *stream);
 
 /* Device time spent in the engine's kernels since the last reset, from HIP events recorded on the
  * submitting stream around each submit_device/submit_slot (milliseconds), and the number of

@@ -501,6 +501,25 @@ extern "C" int itx_engine_export_partial(itx_engine *e, void *d_u64, void *d_u32
     return itx_launch_export(e->t, e->p.mode, e->u64, e->u32, e->L, (uint64_t *)d_u64, (uint32_t *)d_u32, (hipStream_t)stream);
 }
 
+/* the engine's own pair of partial buffers (what itx_engine_finish exports into): for a driver that has no device
+ * allocator of its own — export into them, reduce them across ranks, finish from them */
+extern "C" int itx_engine_partial_buffers(itx_engine *e, void **d_u64, void **d_u32)
+{
+    if (!e || !d_u64 || !d_u32) {
+        itx_set_error("itx_engine_partial_buffers: bad argument");
+        return ITX_E_ARG;
+    }
+    int rc = use_device(e);
+    if (rc) return rc;
+    if (!e->p64) {
+        ITX_HIP(hipMalloc((void **)&e->p64, sizeof(uint64_t) * (partial_u64(e) + 2)));
+        ITX_HIP(hipMalloc((void **)&e->p32, sizeof(uint32_t) * (partial_u32(e) + 4)));
+    }
+    *d_u64 = e->p64;
+    *d_u32 = e->p32;
+    return ITX_OK;
+}
+
 static int ensure_finish_buffers(itx_engine *e)
 {
     const itx_table *t = e->t;

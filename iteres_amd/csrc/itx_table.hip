@@ -37,7 +37,7 @@ void itx_set_error(const char *fmt, ...)
     va_end(ap);
 }
 extern "C" const char *itx_last_error(void) { return g_err; }
-extern "C" int itx_abi_version(void) { return 1004; }
+extern "C" int itx_abi_version(void) { return 1005; }
 extern "C" int itx_device_count(void)
 {
     int n = 0;

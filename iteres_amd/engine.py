@@ -27,6 +27,7 @@ EXPORTS = [
     "itx_bamwin_push", "itx_bamwin_push_begin", "itx_bamwin_push_copied", "itx_bamwin_push_end", "itx_bamwin_patch", "itx_bamwin_truncate", "itx_bamwin_carry", "itx_bamwin_avail", "itx_bamwin_peek", "itx_bamwin_skip",
     "itx_bamwin_parse", "itx_bamwin_fetch", "itx_bamwin_bytes", "itx_bamwin_tids", "itx_bamwin_device_batch",
     "itx_engine_submit_device_own", "itx_engine_wait_own",
+    "itx_engine_partial_buffers", "itx_comm_create", "itx_comm_destroy", "itx_comm_reduce_sum",
 ]
 
 
@@ -94,6 +95,11 @@ def load():
     L.itx_engine_partial_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.itx_engine_export_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.itx_engine_finish_partial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Result)]
+    L.itx_engine_partial_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.itx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.itx_comm_destroy.argtypes = [C.c_void_p]
+    L.itx_comm_destroy.restype = None
+    L.itx_comm_reduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.itx_engine_destroy.argtypes = [C.c_void_p]
     L.itx_engine_destroy.restype = None
     L.itx_engine_set_tidmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

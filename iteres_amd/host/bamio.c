@@ -53,6 +53,17 @@ struct aln_reader {
     int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
     size_t io_off, io_size;
     int io_on, io_state, io_stop, io_buf, io_done;   /* io_state: 0 idle, 1 requested, 2 ready; io_done: the file is read out */
+    /* a share of the file (aln_open_range; one rank of a multi-GPU job): the stream starts at the BGZF block at byte
+     * rg_lo_block of the file, rg_skip inflated bytes into it, and ends where the next share starts: rg_end_off bytes into
+     * the block at rg_end_block (SIZE_MAX: at the end of the file) */
+    int rg_on;
+    size_t rg_lo_block, rg_skip, rg_end_block, rg_end_off, rg_end_csize;
+    size_t io_abs_end;        /* file offset behind the last byte raw_next has delivered                           */
+    size_t dstream_total;     /* inflated bytes of all blocks indexed before the current chunk (from rg_lo_block)  */
+    size_t dskip_left;        /* inflated bytes still to be skipped at the front of the stream                     */
+    int rg_stop_hit, rg_stop_missed, rg_verified;
+    int rg_suspect;           /* something a false start (or damaged input) explains: the share is not to be trusted */
+    void *hz;                 /* while the header is read by the plain host reader (a share that starts inside the file) */
     pthread_t io_thread;
     pthread_mutex_t io_mu;
     pthread_cond_t io_cv;
@@ -73,6 +84,7 @@ struct aln_reader {
         size_t bl_cap, nb;
         const uint8_t *cbase;
         int w, last;
+        size_t trunc;          /* SIZE_MAX, or: the window ends this many fresh bytes in (the share's end boundary) */
     } dj[ITX_BAMWIN_LANES];
     size_t dring_n[ITX_BAMWIN_WINDOWS];
     int dring_eof[ITX_BAMWIN_WINDOWS];
@@ -197,6 +209,165 @@ static int inflate_block(const uint8_t *src, size_t csize, uint8_t *dst, size_t 
     return (rc == Z_STREAM_END && zs.total_out == usize) ? 0 : -1;
 }
 
+/* ---- a plain sequential BGZF reader on the host (pread + one block at a time): the header of a file whose records this
+ * reader takes only a share of, and the search for the share's boundaries. Small amounts of data: no threads. */
+typedef struct {
+    int fd;
+    size_t off, size;          /* the next block starts at file offset off; size of the file                         */
+    uint8_t *u;                /* inflated bytes so far                                                               */
+    size_t len, cap, pos;
+    struct blk *b;             /* the blocks behind u: coff = file offset, csize, uoff, usize                         */
+    size_t nb, bcap;
+} hz_t;
+
+/* inflates the next block behind u[len): 0 done, 1 end of file (or a block cut short by it), -1 not a block / damaged */
+static int hz_block(hz_t *z)
+{
+    uint8_t h[18];
+    if (z->off + 18 > z->size) return 1;
+    if (pread(z->fd, h, 18, (off_t)z->off) != 18) return -1;
+    if (!bgzf_header_ok(h)) return -1;
+    const size_t bsize = (size_t)(h[16] | h[17] << 8) + 1;
+    if (bsize < 26) return -1;
+    if (z->off + bsize > z->size) return 1;
+    uint8_t *c = xmalloc(bsize + 16);
+    if (pread(z->fd, c, bsize, (off_t)z->off) != (ssize_t)bsize) {
+        free(c);
+        return -1;
+    }
+    const size_t usize = rd_u32_at(c + bsize - 4);
+    if (usize > BGZF_MAX) {
+        free(c);
+        return -1;
+    }
+    if (z->len + usize + 64 > z->cap) {
+        z->cap = (z->len + usize) * 2 + BGZF_MAX;
+        z->u = xrealloc(z->u, z->cap);
+    }
+    if (usize && inflate_block(c, bsize, z->u + z->len, usize) != 0) {
+        free(c);
+        return -1;
+    }
+    free(c);
+    if (z->nb == z->bcap) {
+        z->bcap = z->bcap ? z->bcap * 2 : 64;
+        z->b = xrealloc(z->b, sizeof *z->b * z->bcap);
+    }
+    z->b[z->nb].coff = z->off;
+    z->b[z->nb].csize = bsize;
+    z->b[z->nb].uoff = z->len;
+    z->b[z->nb].usize = usize;
+    z->nb++;
+    z->len += usize;
+    z->off += bsize;
+    return 0;
+}
+
+static size_t hz_read(hz_t *z, void *dst, size_t n)
+{
+    while (z->len - z->pos < n)
+        if (hz_block(z) != 0) break;
+    size_t k = z->len - z->pos;
+    if (k > n) k = n;
+    memcpy(dst, z->u + z->pos, k);
+    z->pos += k;
+    return k;
+}
+
+static void hz_free(hz_t *z)
+{
+    free(z->u);
+    free(z->b);
+    memset(z, 0, sizeof *z);
+}
+
+static inline size_t looks_like_record(const uint8_t *u, size_t p, size_t L, int n_targets);
+
+/* Where a share of the file may begin: a point at or after compressed byte `at` where a BAM record starts, as (file offset
+ * of a BGZF block, inflated bytes into that block — fewer than the block holds, size of that block). Two ranks that
+ * call this with the same arguments get the same point, which is all that the split needs: any true record start will do.
+ * It is a GUESS (a block header whose BSIZE chain leads to more headers; 8 well-formed records in a row): the rank whose
+ * share ENDS there verifies it — its own chain of records, which starts at a known record start, has to arrive exactly
+ * there — and the job falls back to one rank when a boundary does not hold. Returns 0 when no such point is found. */
+static int find_split(int fd, size_t fsize, size_t at, int n_targets, size_t *pB, size_t *pc, size_t *pcsize)
+{
+    if (at >= fsize) return 0;
+    const size_t span = fsize - at < (4u << 16) + 64 ? fsize - at : (4u << 16) + 64;
+    uint8_t *buf = xmalloc(span + 32);
+    memset(buf, 0, span + 32);
+    size_t have = 0;
+    while (have < span) {
+        const ssize_t k = pread(fd, buf + have, span - have, (off_t)(at + have));
+        if (k <= 0) break;
+        have += (size_t)k;
+    }
+    size_t B = SIZE_MAX;
+    for (size_t p = 0; p + 18 <= have && p <= (1u << 16); p++) {
+        if (!bgzf_header_ok(buf + p)) continue;
+        size_t q = p;
+        int ok = 1;
+        for (int k = 0; k < 3; k++) {
+            if (at + q == fsize) break;                              /* the chain ends with the file */
+            if (q + 18 > have || !bgzf_header_ok(buf + q)) {
+                ok = 0;
+                break;
+            }
+            const size_t bsize = (size_t)(buf[q + 16] | buf[q + 17] << 8) + 1;
+            if (bsize < 26 || at + q + bsize > fsize) {
+                ok = 0;
+                break;
+            }
+            q += bsize;
+        }
+        if (ok) {
+            B = at + p;
+            break;
+        }
+    }
+    free(buf);
+    if (B == SIZE_MAX) return 0;
+    enum { K = 8, MARGIN = 256u << 10, GIVE_UP = 64u << 20 };
+    hz_t z;
+    memset(&z, 0, sizeof z);
+    z.fd = fd;
+    z.off = B;
+    z.size = fsize;
+    size_t c = 0, found = SIZE_MAX;
+    for (;;) {
+        int st = 0;
+        for (int i = 0; i < 4 && st == 0; i++) st = hz_block(&z);
+        const int at_end = st != 0;
+        const size_t limit = at_end ? z.len : (z.len > MARGIN ? z.len - MARGIN : 0);
+        for (; c < limit && found == SIZE_MAX; c++) {
+            size_t a = c;
+            int k = 0;
+            while (k < K) {
+                const size_t step = looks_like_record(z.u, a, z.len, n_targets);
+                if (!step) break;
+                a += step;
+                k++;
+            }
+            if (k == K || (k > 0 && at_end && a == z.len)) found = c;
+        }
+        if (found != SIZE_MAX || at_end || z.len > GIVE_UP) break;
+    }
+    int ok = 0;
+    if (found != SIZE_MAX) {
+        /* as (block, offset inside it): the block that holds that byte */
+        for (size_t i = 0; i < z.nb; i++)
+            if (z.b[i].usize && found >= z.b[i].uoff && found < z.b[i].uoff + z.b[i].usize) {
+                *pB = z.b[i].coff;
+                *pc = found - z.b[i].uoff;
+                *pcsize = z.b[i].csize;
+                ok = 1;
+                break;
+            }
+    }
+    hz_free(&z);
+    return ok;
+}
+
+
 /* Reads the next chunk of compressed blocks and inflates them in parallel into *pbuf at offset `at` (the buffer is
  * grown as needed, bytes before `at` are kept). Returns the number of bytes inflated; *peof is set when there is no
  * more input (end of file or a damaged block). Touches only the compressed-side state of the reader. */
@@ -266,7 +437,15 @@ static size_t raw_next(aln_reader *r)
                 r->io_fd = fd;
                 r->io_off = 0;
                 r->io_size = (size_t)sb.st_size;
+                if (r->rg_on) {
+                    r->io_off = r->rg_lo_block;
+                    /* the share ends inside the block at rg_end_block: nothing behind that block is this reader's */
+                    if (r->rg_end_block != SIZE_MAX && r->rg_end_block + r->rg_end_csize < r->io_size) r->io_size = r->rg_end_block + r->rg_end_csize;
+                }
+            } else if (r->rg_on) {
+                die("a share of %s was asked for, but it is not a regular file", "the alignment file");
             }
+            r->io_abs_end = r->io_off;
         }
         r->craw[0] = buf_alloc(RAW_HEAD + RAW_STEP + 64);          /* the others when the rotation first reaches them */
         pthread_mutex_init(&r->io_mu, NULL);
@@ -285,6 +464,7 @@ static size_t raw_next(aln_reader *r)
     if (r->clen) memcpy(nb + RAW_HEAD - r->clen, r->cbuf, r->clen);
     r->cbuf = nb + RAW_HEAD - r->clen;
     r->clen += got;
+    r->io_abs_end += got;
     r->io_buf = (r->io_buf + 1) % r->n_raw;
     if (got == RAW_STEP) {
         if (!r->craw[r->io_buf]) {
@@ -435,20 +615,57 @@ static void dev_begin(aln_reader *r)
         r->dblk = xrealloc(r->dblk, sizeof *r->dblk * r->dblk_cap);
         r->dstatus = xrealloc(r->dstatus, r->dblk_cap);
     }
-    for (size_t i = 0; i < nb; i++) {
+    size_t nb_use = nb;
+    j->trunc = SIZE_MAX;
+    int share_done = 0;
+    if (r->rg_on && r->rg_end_block != SIZE_MAX && !r->rg_stop_hit) {
+        /* where the share ends: rg_end_off inflated bytes into the block that starts at file offset rg_end_block. The
+         * record before that point ends exactly there when the boundary is a true record start (checked once the last
+         * window is parsed), so the window is cut there and nothing behind is decoded. */
+        const size_t abs0 = r->io_abs_end - r->clen;
+        for (size_t i = 0; i < nb; i++) {
+            const size_t at = abs0 + r->blk[i].coff;
+            if (at == r->rg_end_block) {
+                r->rg_stop_hit = 1;
+                j->trunc = r->blk[i].uoff + r->rg_end_off;
+                if (j->trunc > r->blk[i].uoff + r->blk[i].usize) {      /* the boundary lies behind the block's bytes: not this stream's */
+                    r->rg_stop_missed = 1;
+                    j->trunc = r->blk[i].uoff;
+                }
+                nb_use = i + 1;
+                share_done = 1;
+                break;
+            }
+            if (at > r->rg_end_block) {                                 /* the chain of blocks steps over it: a false boundary */
+                r->rg_stop_missed = 1;
+                nb_use = i;
+                j->trunc = r->blk[i].uoff;
+                share_done = 1;
+                break;
+            }
+        }
+        if (share_done) {
+            off = nb_use < nb ? r->blk[nb_use].coff : off;
+            utot = nb_use ? r->blk[nb_use - 1].uoff + r->blk[nb_use - 1].usize : 0;
+            r->dmore = 0;
+        }
+    }
+    for (size_t i = 0; i < nb_use; i++) {
         j->bl[i] = r->blk[i];
         r->dblk[i].coff = (uint32_t)r->blk[i].coff;
         r->dblk[i].csize = (uint32_t)r->blk[i].csize;
         r->dblk[i].uoff = (uint32_t)r->blk[i].uoff;
         r->dblk[i].usize = (uint32_t)r->blk[i].usize;
     }
-    j->nb = nb;
+    r->dstream_total += utot;
+    j->nb = nb_use;
     j->cbase = r->cbuf;
     j->w = (int)(k % ITX_BAMWIN_WINDOWS);
-    j->last = damaged || (got == 0 && nb == 0);
+    j->last = damaged || share_done || (got == 0 && nb == 0);
+    if (damaged && r->rg_on) r->rg_suspect = 1;
     static const uint8_t none[16];
     tq = now_s();
-    DEV_CHK(dev.push_begin(dev.ctx, j->w, (int)(k % ITX_BAMWIN_LANES), r->clen ? r->cbuf : none, off, r->dblk, nb), "push");
+    DEV_CHK(dev.push_begin(dev.ctx, j->w, (int)(k % ITX_BAMWIN_LANES), r->clen ? r->cbuf : none, off, r->dblk, nb_use), "push");
     t_inflate += now_s() - tq;
     r->cbuf += off;
     r->clen -= off;
@@ -478,9 +695,14 @@ static void dev_end(aln_reader *r)
                 break;
             }
         }
+    if (j->trunc != SIZE_MAX && !damaged && j->trunc <= n_new) {
+        DEV_CHK(dev.truncate(dev.ctx, j->w, j->trunc), "truncate");
+        n_new = j->trunc;
+    }
     t_inflate += now_s() - tq;
     r->dring_n[j->w] = n_new;
     r->dring_eof[j->w] = j->last || damaged;
+    if (damaged && r->rg_on) r->rg_suspect = 1;
 }
 
 /* The producer (read-ahead thread): begin a push whenever a window and a lane are free and input is left, end the oldest
@@ -539,7 +761,28 @@ static size_t dev_advance(aln_reader *r)
         pthread_mutex_unlock(&r->pf_mu);
     }
     const int w = (int)(nxt % ITX_BAMWIN_WINDOWS);
-    if (r->dk_cur >= 0) DEV_CHK(dev.carry(dev.ctx, r->dw, w), "carry");
+    if (r->dk_cur >= 0) {
+        if (r->rg_on && r->rg_lo_block) {
+            /* a share that starts at a guessed record start: a record "too long to carry" is what a false start looks
+             * like — the share ends here, unverified, and the job is done again by one rank */
+            if (dev.carry(dev.ctx, r->dw, w) != 0) {
+                r->rg_suspect = 1;
+                r->eof = 1;
+                r->dlast = 1;
+                if (r->pf_on) pthread_mutex_lock(&r->pf_mu);
+                r->dk_cur = nxt;
+                if (r->pf_on) {
+                    pthread_cond_broadcast(&r->pf_cv);
+                    pthread_mutex_unlock(&r->pf_mu);
+                }
+                r->dparsed = 1;
+                r->dn_rec = r->drec_next = 0;
+                return 0;
+            }
+        } else {
+            DEV_CHK(dev.carry(dev.ctx, r->dw, w), "carry");
+        }
+    }
     if (r->pf_on) pthread_mutex_lock(&r->pf_mu);
     r->dk_cur = nxt;
     if (r->pf_on) {
@@ -550,6 +793,13 @@ static size_t dev_advance(aln_reader *r)
     r->dparsed = 0;
     r->dn_rec = r->drec_next = 0;
     if (r->dring_eof[w]) r->eof = 1;
+    if (r->dskip_left) {                                           /* a share starts rg_skip bytes into its first block */
+        size_t av = 0;
+        DEV_CHK(dev.avail(dev.ctx, w, &av), "avail");
+        const size_t sk = av < r->dskip_left ? av : r->dskip_left;
+        DEV_CHK(dev.skip(dev.ctx, w, sk), "skip");
+        r->dskip_left -= sk;
+    }
     return r->dring_n[w];
 }
 
@@ -681,6 +931,7 @@ static size_t bgzf_load_chunk(aln_reader *r)
 /* sequential read of n bytes (header parsing) */
 static size_t bgzf_read(aln_reader *r, void *dst, size_t n)
 {
+    if (r->hz) return hz_read((hz_t *)r->hz, dst, n);
     if (r->dev) return dev_read(r, dst, n);
     while (r->ulen - r->upos < n) {
         if (bgzf_load_chunk(r) == 0 && r->eof) break;
@@ -691,6 +942,7 @@ static size_t bgzf_read(aln_reader *r, void *dst, size_t n)
     r->upos += k;
     return k;
 }
+
 
 static char *xstrndup_bound(const char *s, size_t max)
 {
@@ -807,6 +1059,123 @@ aln_reader *aln_open(const char *path, int is_sam)
     }
     for (int i = 0; i < r->n_targets; i++) names_intern(&r->tnames, r->tname[i]);    /* first occurrence wins a lookup */
     return r;
+}
+
+/* A share of a BAM file for one rank of a multi-GPU job: the records that START in the compressed byte range [lo, hi) of
+ * the file — more exactly between the split points find_split gives for lo and for hi (hi = SIZE_MAX: up to the end).
+ * Device decoder only. The header is read like any reader's (every rank needs the reference list). */
+aln_reader *aln_open_range(const char *path, size_t lo, size_t hi)
+{
+    if (lo == 0 && hi == SIZE_MAX) return aln_open(path, 0);
+    if (!dev.push_begin) die("a share of %s was asked for without the device decoder", path);
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    struct stat sb;
+    if (fstat(fileno(f), &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        fclose(f);
+        return NULL;
+    }
+    const size_t fsize = (size_t)sb.st_size;
+    ld_probe();
+    aln_reader *r = xcalloc(1, sizeof *r);
+    r->f = f;
+    r->pending_len = -1;
+    names_init(&r->tnames);
+    r->dev = 1;
+    r->dk_cur = -1;
+    r->rg_on = 1;
+    r->rg_end_block = SIZE_MAX;
+    for (int w = 0; w < ITX_BAMWIN_WINDOWS; w++) {
+        size_t left = 0;
+        DEV_CHK(dev.avail(dev.ctx, w, &left), "avail");
+        DEV_CHK(dev.skip(dev.ctx, w, left), "skip");
+    }
+    /* the reference list, by the plain host reader (a few blocks) */
+    hz_t z;
+    memset(&z, 0, sizeof z);
+    z.fd = fileno(f);
+    z.size = fsize;
+    r->hz = &z;
+    int rc = bam_read_header(r);
+    r->hz = NULL;
+    hz_free(&z);
+    if (rc != 0) {
+        aln_close(r);
+        return NULL;
+    }
+    int empty = 0;
+    size_t B = 0, c = 0, cs = 0;
+    if (hi != SIZE_MAX && hi < fsize && find_split(fileno(f), fsize, hi, r->n_targets, &B, &c, &cs)) {
+        r->rg_end_block = B;
+        r->rg_end_off = c;
+        r->rg_end_csize = cs;
+    }
+    if (lo > 0) {
+        if (!find_split(fileno(f), fsize, lo, r->n_targets, &B, &c, &cs)) {
+            empty = 1;                                             /* no record starts behind lo: the share before this one runs to the end */
+        } else {
+            if (r->rg_end_block != SIZE_MAX && (B > r->rg_end_block || (B == r->rg_end_block && c >= r->rg_end_off))) empty = 1;
+            r->rg_lo_block = B;
+            r->dskip_left = c;
+            r->dparsed = 1;                                        /* nothing to parse before the first window is in */
+        }
+    } else {
+        /* from the start of the file: the header goes by once more, in front of the records, through the device's windows */
+        for (int i = 0; i < r->n_targets; i++) free(r->tname[i]);
+        free(r->tname);
+        r->tname = NULL;
+        r->n_targets = 0;
+        if (bam_read_header(r) != 0) {
+            aln_close(r);
+            return NULL;
+        }
+        DEV_CHK(dev.skip(dev.ctx, r->dw, r->hdr_pos), "skip");
+        free(r->hdr);
+        r->hdr = NULL;
+        r->hdr_len = r->hdr_pos = 0;
+    }
+    if (empty) {
+        r->eof = 1;
+        r->dlast = 1;
+        r->dparsed = 1;
+        r->rg_verified = 1;
+    }
+    for (int i = 0; i < r->n_targets; i++) names_intern(&r->tnames, r->tname[i]);
+    return r;
+}
+
+/* find_split for callers outside this file (the CPU test tool): the reference list is read first, like aln_open_range does */
+int aln_find_split(const char *path, size_t at, size_t *block, size_t *off, size_t *csize)
+{
+    FILE *f = fopen(path, "rb");
+    struct stat sb;
+    if (!f || fstat(fileno(f), &sb) != 0) return -1;
+    ld_probe();
+    aln_reader *r = xcalloc(1, sizeof *r);
+    r->f = f;
+    r->pending_len = -1;
+    names_init(&r->tnames);
+    hz_t z;
+    memset(&z, 0, sizeof z);
+    z.fd = fileno(f);
+    z.size = (size_t)sb.st_size;
+    r->hz = &z;
+    const int rc = bam_read_header(r);
+    r->hz = NULL;
+    hz_free(&z);
+    int found = -1;
+    if (rc == 0) found = find_split(fileno(f), (size_t)sb.st_size, at, r->n_targets, block, off, csize);
+    aln_close(r);
+    return found;
+}
+
+/* after the last batch: 1 when the share's end boundary held (the record chain arrived exactly there) or it has none */
+int aln_range_verified(const aln_reader *r)
+{
+    if (!r->rg_on) return 1;
+    if (r->rg_suspect) return 0;
+    if (r->rg_end_block == SIZE_MAX) return 1;
+    return r->rg_verified == 1;
 }
 
 void aln_close(aln_reader *r)
@@ -1138,10 +1507,21 @@ static int dev_ensure_records(aln_reader *r)
             r->d_rewalked += redo;
             r->dflags = flags;
             r->dseen_ok = 0;
-            if (malformed) r->dlast = 1;                       /* bam.c:186-190: nothing after this window counts */
+            if (malformed) {
+                r->dlast = 1;                                  /* bam.c:186-190: nothing after this window counts */
+                if (r->rg_on) r->rg_suspect = 1;               /* ... of the whole file: the other shares must not count either */
+            }
             continue;
         }
-        if (r->dlast || r->eof) return 0;                      /* end of input (a truncated tail record is dropped) */
+        if (r->dlast || r->eof) {                              /* end of input (a truncated tail record is dropped) */
+            if (r->rg_on && r->rg_end_block != SIZE_MAX && !r->rg_verified) {
+                /* the share's end is a true record start iff the chain of records arrives exactly there: nothing is left over */
+                size_t left = 1;
+                DEV_CHK(dev.avail(dev.ctx, r->dw, &left), "avail");
+                r->rg_verified = (r->rg_stop_hit && !r->rg_stop_missed && !r->dlast && left == 0 && r->dskip_left == 0) ? 1 : -1;
+            }
+            return 0;
+        }
         dev_advance(r);
     }
     return 1;

@@ -246,7 +246,7 @@ int main_cpgstat(int argc, char **argv)
     char *outStat = fmt_name(output, ".CpG.subfamily.stat"), *outFam = fmt_name(output, ".CpG.family.stat");
     char *outCla = fmt_name(output, ".CpG.class.stat");
 
-    gpu_warmup_start(0, NULL, 0);
+    gpu_warmup_start(0, NULL, 0, 0);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(chr_size_file, &chr_sizes);
     sizes_load(rep_size_file, &rep_sizes);
@@ -426,7 +426,7 @@ int main_cpgfilter(int argc, char **argv)
         fprintf(stderr, "* You didn't specify any filter, will output all repeats\n");
         filter_field = 0;
     }
-    gpu_warmup_start(0, NULL, 0);
+    gpu_warmup_start(0, NULL, 0, 0);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(chr_size_file, &chr_sizes);
     sizes_load(rep_size_file, &rep_sizes);

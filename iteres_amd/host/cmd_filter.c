@@ -100,7 +100,10 @@ int main_filter(int argc, char **argv)
         free(copy);
     }
 
-    gpu_warmup_start(!o.is_sam, o.aln_arg, 0);
+    /* what is order-dependent stays with one rank: -R, the read-name lists (-r), SAM text */
+    const int splittable = !o.is_sam && !o.dedup && !optreadlist;
+    multi_begin(splittable, o.aln_arg, 0);
+    gpu_warmup_start(!o.is_sam, o.aln_arg, 0, splittable);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);
@@ -129,7 +132,7 @@ int main_filter(int argc, char **argv)
     memset(&res, 0, sizeof res);
     res.cnt = cnt;
     res.locus_cnt = xcalloc(rm.n_rows + 1, sizeof(uint32_t));
-    if (itx_engine_finish(eng, &res) != ITX_OK) die("itx_engine_finish: %s", itx_last_error());
+    if (stream_finish(eng, &res) != ITX_OK) die("itx_engine_finish: %s", itx_last_error());
     cnt[11] -= hc.dup_unique;                     /* reads_nonredundant_unique: -R duplicates never reach it (generic.c:524-539) */
     write_filter_out(&rm, res.locus_cnt, locus_names, out, optreadlist, optthreshold, subfam, cnt[nindex]);
     fprintf(stderr, "* Preparing report file\n");

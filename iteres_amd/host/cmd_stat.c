@@ -129,7 +129,10 @@ int main_stat(int argc, char **argv)
 
     const int timing = getenv("ITX_TIMING") != NULL;
     const double t_begin = now_s();
-    gpu_warmup_start(!o.is_sam, o.aln_arg, 1);
+    /* what is order-dependent stays with one rank: -R, the bed files, SAM text; everything else shards by record */
+    const int splittable = !o.is_sam && !o.dedup && !optBed && !optBedUniq;
+    multi_begin(splittable, o.aln_arg, 1);
+    gpu_warmup_start(!o.is_sam, o.aln_arg, 1, splittable);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);
@@ -158,7 +161,7 @@ int main_stat(int argc, char **argv)
     res.cla_cnt = xcalloc(2 * (size_t)rm.clas.n + 1, sizeof(uint64_t));
     res.cov = xcalloc(info.cov_len + 1, sizeof(uint32_t));
     res.cov_uniq = xcalloc(info.cov_len + 1, sizeof(uint32_t));
-    if (itx_engine_finish(eng, &res) != ITX_OK) die("itx_engine_finish: %s", itx_last_error());
+    if (stream_finish(eng, &res) != ITX_OK) die("itx_engine_finish: %s", itx_last_error());
     const double t_finished = now_s();
     cnt[11] -= hc.dup_unique;                     /* reads_nonredundant_unique: -R duplicates never reach it (generic.c:907-922) */
     cnt[12] = hc.diff_subfam;                     /* reads_diff_subfam (generic.c:978) */

@@ -16,6 +16,9 @@
 /* ---- errors: cuskent/errabort.c:166-199 — message + newline to stderr, exit(-1) */
 void die(const char *fmt, ...) __attribute__((noreturn, format(printf, 1, 2)));
 void warnf(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+extern FILE *itx_err_stream;             /* where die / warnf write when not stderr (ranks > 0 of a multi-GPU job) */
+extern const char *itx_err_prefix;
+extern void (*itx_die_hook)(void);        /* run by die() before it leaves (rank 0 ends the ranks it started) */
 void *xmalloc(size_t n);
 void *xcalloc(size_t n, size_t sz);
 void *xrealloc(void *p, size_t n);
@@ -104,6 +107,14 @@ size_t aln_device_left(const aln_reader *r);  /* device decoder: records of the 
 int aln_device_exhausted(aln_reader *r);
 void aln_readahead(aln_reader *r);            /* BAM: start decoding ahead of the first aln_read_batch */     /* device decoder: 1 when no record is left */
 aln_reader *aln_open(const char *path, int is_sam);          /* NULL when the file cannot be opened / has no header */
+/* One rank's share of a BAM file (multi-GPU; device decoder): the records that start between the split points of the
+ * compressed byte offsets lo and hi (hi = SIZE_MAX: to the end; (0, SIZE_MAX) is aln_open). aln_range_verified, after the
+ * last batch: 1 when the share's end boundary proved to be a true record start (or the share runs to the end of the file). */
+aln_reader *aln_open_range(const char *path, size_t lo, size_t hi);
+int aln_range_verified(const aln_reader *r);
+/* the split point at or after compressed byte `at` (1 found: BGZF block at file offset *block, *off inflated bytes into it,
+ * the block takes *csize bytes; 0 none before the end of the file; -1 the file cannot be read) */
+int aln_find_split(const char *path, size_t at, size_t *block, size_t *off, size_t *csize);
 void aln_close(aln_reader *r);
 int aln_n_targets(const aln_reader *r);
 const char *aln_target_name(const aln_reader *r, int tid);
@@ -155,7 +166,7 @@ char *filename_without_ext(const char *path);
 /* Runs the record loop (generic.c:700-1062 / 343-697) over one or more files through the engine.
  * progress_every: 100000 (stat, generic.c:760) or 10000 (filter, generic.c:397). want_qnames: per-locus read
  * names (filter -r): *locus_names[row] receives a comma-joined list in BAM order. */
-void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file);  /* starts the HIP runtime on a helper thread (and, for BAM input, the device inflater with its
+void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file, int splittable);  /* starts the HIP runtime on a helper thread (and, for BAM input, the device inflater with its
                                         * page-locked buffers); run_stream joins it */
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
                 unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names,
@@ -176,6 +187,25 @@ void write_bigwig(const char *path, const char *wig_name, const char *const *nam
                   size_t n_names);
 /* tables.c: a whole text file in memory, through the same openers as the rmsk file (plain, .gz/.Z, .bz2, .zip) */
 char *slurp_text(const char *path, size_t *len);
+
+/* ---- multi.c: one process per GPU. `iteres stat|filter` starts N - 1 more copies of itself (ranks 1..N-1, GPU r each;
+ * N = ITX_GPUS, default: every GPU the process may use, as far as the input is worth sharing; ITX_GPU_MAP=a,b,.. names
+ * other devices) before anything touches a GPU; a launcher that starts the ranks
+ * itself (bench.py under torch.distributed.run) sets ITX_RANK / ITX_WORLD / ITX_DEVICE / ITX_COMM_ID / ITX_EXCHANGE instead.
+ * Every rank parses the same inputs, holds a replica of the table and takes its share of the alignment files' compressed
+ * bytes (stream.c); ONE sum-reduce of the engines' partials onto rank 0 ends the stream (include/iteres_amd.h: itx_comm_*),
+ * rank 0 writes the files, the others leave. */
+void multi_early(int argc, char **argv);            /* from main(): picks up a launcher's rank, quiets ranks > 0 */
+void multi_begin(int splittable, const char *aln_arg, int multi_file);   /* after the options are known, before the first GPU call: starts the other ranks */
+size_t multi_min_share(void);                       /* compressed bytes below which a share is not worth a rank (ITX_SPLIT_MIN) */
+void multi_finish(void);                            /* rank 0, before it returns: the ranks it started have all left */
+int multi_rank(void);
+int multi_world(void);
+int multi_device(void);
+int multi_comm_mode(void);
+const char *multi_comm_id(void);
+/* stream.c: what the writers read — itx_engine_finish, or, after a multi-GPU stream, the same from the reduced partial */
+int stream_finish(itx_engine *eng, const itx_result *res);
 
 int main_cpgstat(int argc, char **argv);
 int main_cpgfilter(int argc, char **argv);

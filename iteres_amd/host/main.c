@@ -25,6 +25,7 @@ static int usage(void)
 int main(int argc, char *argv[])
 {
     if (argc < 2) return usage();
+    multi_early(argc, argv);
     /* host threads (BGZF inflate, record parse, bigWig deflate): OMP_NUM_THREADS when given, else the processors this
      * process may run on, capped — the decode saturates long before a big host's core count and idle OpenMP workers
      * spinning on a shared box cost more than they give */
@@ -42,5 +43,6 @@ int main(int argc, char *argv[])
         fprintf(stderr, "[iteres] unrecognized command '%s'\n", argv[1]);
         return 1;
     }
+    multi_finish();
     return rc;
 }

@@ -8,6 +8,8 @@
 
 #include <errno.h>
 #include <stdlib.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <string.h>
 #include <strings.h>
 #include <time.h>
@@ -28,6 +30,8 @@ static pthread_t warm_thread;
 static int warm_on, warm_bam;
 static char *warm_first;                      /* the first alignment file, opened (and decoded ahead) by the helper thread */
 static aln_reader *warm_reader;
+static int warm_single;                       /* the argument names one file */
+static size_t warm_lo, warm_hi = SIZE_MAX;    /* the share the helper thread opened it with */
 
 /* BAM input is decoded on the device (include/iteres_amd.h: itx_bamwin_*: blocks inflated, records located and parsed
  * there) unless ITX_HOST_INFLATE is set. The reader's compressed-chunk buffers then have to be page-locked, which takes
@@ -68,13 +72,52 @@ static void use_device_reader(void)
     aln_use_device(&ops);
 }
 
+/* ---- the shares of a multi-GPU job: the compressed bytes of all alignment files, laid end to end, are cut into
+ * multi_world() equal ranges; a rank takes, of every file, what falls into its range (aln_open_range turns the byte
+ * offsets into record boundaries). One rank: everything. */
+typedef struct {
+    size_t lo, hi;             /* hi = SIZE_MAX: to the end of the file; lo == hi: nothing of this file */
+} share_t;
+
+/* sh[fi] for this rank; returns 0 when the job cannot be shared (then rank 0 has everything, the others nothing) */
+static int plan_shares(char **files, int n_files, int splittable, int rank, int world, share_t *sh)
+{
+    for (int i = 0; i < n_files; i++) {
+        sh[i].lo = 0;
+        sh[i].hi = rank == 0 ? SIZE_MAX : 0;
+    }
+    if (world <= 1) return 1;
+    if (!splittable) return 0;
+    size_t size[100], total = 0;
+    for (int i = 0; i < n_files; i++) {
+        struct stat sb;
+        if (stat(files[i], &sb) != 0 || !S_ISREG(sb.st_mode)) return 0;       /* a pipe, or a file that is not there (reported where the reference does) */
+        size[i] = (size_t)sb.st_size;
+        total += size[i];
+    }
+    if (total / (size_t)world < multi_min_share()) return 0;
+    const size_t g0 = (size_t)((__uint128_t)total * (unsigned)rank / (unsigned)world), g1 = (size_t)((__uint128_t)total * ((unsigned)rank + 1) / (unsigned)world);
+    size_t base = 0;
+    for (int i = 0; i < n_files; i++) {
+        const size_t a = g0 > base ? g0 - base : 0, b = g1 > base ? g1 - base : 0;
+        sh[i].lo = a < size[i] ? a : size[i];
+        sh[i].hi = b < size[i] ? b : SIZE_MAX;
+        if (sh[i].hi != SIZE_MAX && sh[i].hi <= sh[i].lo) sh[i].lo = sh[i].hi = 0;
+        if (sh[i].lo >= size[i]) sh[i].lo = sh[i].hi = 0;
+        base += size[i];
+    }
+    return 1;
+}
+
+static int warm_splittable;
+
 static void *warm_main(void *arg)
 {
     (void)arg;
     const double a = now_s();
     const int ndev = itx_device_count();
     const double b = now_s();
-    if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(0, &g_inflater) == ITX_OK) {
+    if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(multi_device(), &g_inflater) == ITX_OK) {
         /* the compressed chunks the reader rotates through (one being read, the others being decoded) */
         const char *ce = getenv("ITX_BGZF_CHUNK");
         const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
@@ -91,7 +134,16 @@ static void *warm_main(void *arg)
         /* the first file's header, and its first windows decoded while the main thread is still parsing the rmsk file; a
          * file that does not open is left to run_stream, which reports it where the reference does */
         use_device_reader();
-        warm_reader = aln_open(warm_first, 0);
+        share_t sh0;
+        char *one[1] = {warm_first};
+        /* this rank's share of the FIRST file when the list has one file (the common case); longer lists are opened by the loop */
+        if (multi_world() <= 1) {
+            warm_reader = aln_open(warm_first, 0);
+        } else if (warm_single && plan_shares(one, 1, warm_splittable, multi_rank(), multi_world(), &sh0) && sh0.lo != sh0.hi) {
+            warm_reader = aln_open_range(warm_first, sh0.lo, sh0.hi);
+            warm_lo = sh0.lo;
+            warm_hi = sh0.hi;
+        }
         if (warm_reader) aln_readahead(warm_reader);
     }
     if (getenv("ITX_TIMING"))
@@ -99,12 +151,14 @@ static void *warm_main(void *arg)
                 c - b, now_s() - c);
     return NULL;
 }
-void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file)
+void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file, int splittable)
 {
     warm_bam = bam_input;
+    warm_splittable = splittable;
     if (bam_input && aln_arg) {
         warm_first = xstrdup(aln_arg);
         char *c = multi_file ? strchr(warm_first, ',') : NULL;
+        warm_single = c == NULL;
         if (c) *c = 0;
     }
     if (!warm_on && pthread_create(&warm_thread, NULL, warm_main, NULL) == 0) warm_on = 1;
@@ -179,6 +233,15 @@ static void side_release(aln_side *side, size_t n, int keep_qnames)
     }
 }
 
+/* after a multi-GPU stream: the reduced partial (the engine's own buffers) the writers' arrays come from */
+static void *g_reduced_u64, *g_reduced_u32;
+
+int stream_finish(itx_engine *eng, const itx_result *res)
+{
+    if (g_reduced_u64) return itx_engine_finish_partial(eng, g_reduced_u64, g_reduced_u32, res);
+    return itx_engine_finish(eng, res);
+}
+
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,
                 unsigned progress_every, int want_qnames, itx_engine **eng_out, itx_table **tab_out, char ***locus_names,
                 host_counts *hc)
@@ -192,7 +255,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     const uint32_t n_chrom = chr_sizes->names.n;
     itx_table *tab = NULL;
     size_t bad = 0;
-    int rc = itx_table_create(rm->rows, rm->n_rows, chr_sizes->value, (int)n_chrom, rm->rep_len, rm->reps.n, rm->fams.n, rm->clas.n, 0,
+    int rc = itx_table_create(rm->rows, rm->n_rows, chr_sizes->value, (int)n_chrom, rm->rep_len, rm->reps.n, rm->fams.n, rm->clas.n, multi_device(),
                               &tab, &bad);
     if (rc == ITX_E_RANGE) {
         const itx_row *r = &rm->rows[bad];
@@ -268,21 +331,44 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     }
     names_t warned;
     names_init(&warned);
+    /* this rank's share of every file (one rank: all of it) */
+    share_t share[100];
+    const int world = multi_world(), rank = multi_rank();
+    int shared = plan_shares(files, n_files, warm_splittable && !getenv("ITX_HOST_INFLATE"), rank, world, share) && world > 1;
+    unsigned long long boundary_missed = 0;
     /* the helper thread (HIP start-up, device decoder, first file opened and decoding ahead) has had the rmsk parse and the
      * table build to finish */
     const double t_join = now_s();
     gpu_warmup_join();
     if (timing) fprintf(stderr, "[itx timing] waited %.3f s for the helper thread\n", now_s() - t_join);
     if (g_inflater) use_device_reader();
+    if (shared && !g_inflater) die("rank %d: the device decoder did not come up: %s", rank, itx_last_error());
+    /* pass 0: this rank's shares, then the exchange. pass 1 (rank 0 only, and only when a share boundary did not hold —
+     * the split points are guesses that the rank before verifies): the whole job again by this rank alone */
+    for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+        if (!boundary_missed) break;
+        fprintf(stderr, "[iteres] note: a share boundary was not a record start; scanning the input again with one GPU\n");
+        chk(itx_engine_reset(eng), "itx_engine_reset");
+        if (hc) hc->diff_subfam = hc->dup_unique = 0;
+        ends = 0;
+        for (int i = 0; i < n_files; i++) share[i].lo = 0, share[i].hi = SIZE_MAX;
+        shared = 0;
+    }
     for (int fi = 0; fi < n_files; fi++) {
         if (multi_file) fprintf(stderr, "\n* Processing %s\n", files[fi]);
+        if (share[fi].lo == share[fi].hi) continue;                      /* nothing of this file is this rank's */
         const double t_open0 = now_s();
         aln_reader *rd = NULL;
-        if (fi == 0 && warm_reader && warm_first && strcmp(files[0], warm_first) == 0) {
+        if (fi == 0 && pass == 0 && warm_reader && warm_first && strcmp(files[0], warm_first) == 0 && warm_lo == share[0].lo && warm_hi == share[0].hi) {
             rd = warm_reader;                                            /* opened and decoding since the helper thread came up */
             warm_reader = NULL;
         } else {
-            rd = aln_open(files[fi], o->is_sam);
+            if (warm_reader && fi == 0 && pass == 0) {                   /* opened for another share than this plan's: not used */
+                aln_close(warm_reader);
+                warm_reader = NULL;
+            }
+            rd = (share[fi].lo == 0 && share[fi].hi == SIZE_MAX) ? aln_open(files[fi], o->is_sam) : aln_open_range(files[fi], share[fi].lo, share[fi].hi);
         }
         const double t_opened = now_s();
         if (!rd) {
@@ -483,10 +569,46 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         free(t2id);
         free(t2c);
         const double t_drained = now_s();
+        if (!aln_range_verified(rd)) boundary_missed++;
         aln_close(rd);
         if (timing)
             fprintf(stderr, "[itx timing] open %.3f s, record loop %.3f s, drain %.3f s, close %.3f s\n", t_opened - t_open0, t_loop_done - t_opened,
                     t_drained - t_loop_done, now_s() - t_drained);
+    }
+    if (pass == 1 || world <= 1) break;
+    {
+        /* ---- the ONE exchange: every rank's partial, summed onto rank 0 (RCCL over xGMI) */
+        const double tx = now_s();
+        void *p64 = NULL, *p32 = NULL;
+        uint64_t n64 = 0, n32 = 0;
+        chk(itx_engine_partial_buffers(eng, &p64, &p32), "itx_engine_partial_buffers");
+        chk(itx_engine_partial_size(eng, &n64, &n32), "itx_engine_partial_size");
+        chk(itx_engine_sync(eng), "itx_engine_sync");
+        chk(itx_engine_export_partial(eng, p64, p32, NULL), "itx_engine_export_partial");
+        uint64_t meta[4] = {hc ? hc->diff_subfam : 0, hc ? hc->dup_unique : 0, boundary_missed, ends};
+        itx_comm *comm = NULL;
+        const double tc = now_s();
+        chk(itx_comm_create(rank, world, multi_device(), multi_comm_id(), multi_comm_mode(), &comm), "itx_comm_create");
+        const double ty = now_s();
+        chk(itx_comm_reduce_sum(comm, p64, n64, p32, n32, meta, 4, NULL), "itx_comm_reduce_sum");
+        if (timing && rank == 0)
+            fprintf(stderr, "[itx timing] exchange (%s): export %.3f s, communicator %.3f s, reduce of %.1f MB per rank (waits for the slowest rank) %.3f s\n",
+                    multi_comm_mode() == ITX_COMM_FILE ? "files" : "RCCL", tc - tx, ty - tc, (double)(n64 * 8 + n32 * 4) / 1e6, now_s() - ty);
+        itx_comm_destroy(comm);
+        if (rank > 0) {                                              /* handed over: rank 0 writes the files */
+            fflush(NULL);
+            _exit(0);
+        }
+        if (hc) {
+            hc->diff_subfam = meta[0];
+            hc->dup_unique = meta[1];
+        }
+        boundary_missed = meta[2];
+        if (!boundary_missed) {
+            g_reduced_u64 = p64;
+            g_reduced_u32 = p32;
+        }
+    }
     }
     names_free(&warned);
     names_free(&chr_names);

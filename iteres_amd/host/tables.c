@@ -15,14 +15,22 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+/* multi.c: a rank other than 0 keeps its banners to itself (stderr is /dev/null there) but not its errors */
+FILE *itx_err_stream;
+const char *itx_err_prefix;
+void (*itx_die_hook)(void);
+#define ERR_OUT (itx_err_stream ? itx_err_stream : stderr)
+
 void die(const char *fmt, ...)
 {
     va_list ap;
     fflush(stdout);
+    if (itx_err_prefix) fputs(itx_err_prefix, ERR_OUT);
     va_start(ap, fmt);
-    vfprintf(stderr, fmt, ap);
+    vfprintf(ERR_OUT, fmt, ap);
     va_end(ap);
-    fputc('\n', stderr);
+    fputc('\n', ERR_OUT);
+    if (itx_die_hook) itx_die_hook();
     /* errAbort ends with exit(-1) (errabort.c:166-172): status 255. Here other threads may be busy (OpenMP workers, the
      * loader, the HIP runtime starting up on the warm-up thread) and exit()'s teardown would race with them: flush what
      * stdio holds and leave at once with the same status. */
@@ -33,10 +41,11 @@ void die(const char *fmt, ...)
 void warnf(const char *fmt, ...)
 {
     va_list ap;
+    if (itx_err_prefix) fputs(itx_err_prefix, ERR_OUT);
     va_start(ap, fmt);
-    vfprintf(stderr, fmt, ap);
+    vfprintf(ERR_OUT, fmt, ap);
     va_end(ap);
-    fputc('\n', stderr);
+    fputc('\n', ERR_OUT);
 }
 
 void *xmalloc(size_t n)

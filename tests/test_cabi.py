@@ -31,7 +31,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version_and_error_paths(lib):
-    assert lib.itx_abi_version() == 1004
+    assert lib.itx_abi_version() == 1005
     assert lib.itx_table_get_info(None, None) == -1                 # ITX_E_ARG
     assert b"null" in lib.itx_last_error()
     h = C.c_void_p()

@@ -1,0 +1,195 @@
+"""The command as a multi-GPU job (one process per GPU, iteres_amd/host/multi.c + stream.c), rehearsed on ONE GPU: the
+ranks share device 0 (ITX_GPU_MAP=0,0,...) and hand their partials over through files instead of RCCL (which wants a GPU per
+rank) — everything else is the code an 8-GPU node runs: the ranks the command starts itself (ITX_GPUS) or a launcher
+starts (ITX_RANK / ITX_WORLD), the shares of the compressed bytes, split points guessed by one rank and verified by the rank
+before it, the fall-back to one rank when a guess does not hold, the reduced partial turned into the reference's files.
+Every run must reproduce the reference's files byte for byte (tests/golden) or the one-rank run's."""
+import filecmp
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import goldencase as gc
+import refio
+from iteres_amd import build, engine as eng, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def exe():
+    lib, exe = build.build_all()
+    assert exe and os.path.exists(exe)
+    return exe
+
+
+def _ranks_env(n, **kw):
+    e = dict(os.environ, ITX_GPUS=str(n), ITX_GPU_MAP=",".join("0" for _ in range(n)), ITX_SPLIT_MIN="1", ITX_TIMING="1", ITX_COMM_TIMEOUT="120")
+    e.update(kw)
+    return e
+
+
+BAM_RUNS = [(c, r) for c, r in gc.list_runs() if gc.manifest_run(c, r)["cmd"] in ("stat", "filter") and gc.manifest_run(c, r)["aln"].endswith(".bam")]
+
+
+@pytest.mark.parametrize("case,run_name", BAM_RUNS)
+def test_ranks_reproduce_reference_files(case, run_name, exe, tmp_path):
+    """Every golden option set that reads a BAM, as a job of 3 ranks with the decoder cutting the file into small chunks:
+    the reference's files, byte for byte. Option sets that are order-dependent (-R, bed files, -r) must quietly stay with
+    one rank."""
+    run = gc.manifest_run(case, run_name)
+    src = os.path.join(gc.GOLDEN, case, "in")
+    paths = [refio.materialise(src, n, str(tmp_path)) for n in ["chrom.sizes", "rep.sizes", "rmsk.txt", run["aln"]]]
+    work = tmp_path / "out"
+    work.mkdir()
+    pr = subprocess.run([exe, run["cmd"]] + run["opts"] + ["-o", run["prefix"]] + paths, cwd=work, capture_output=True, text=True, timeout=600,
+                        env=_ranks_env(3, ITX_BGZF_CHUNK="40000"))
+    assert pr.returncode == run["rc"], pr.stderr[-2000:]
+    for fn in run["files"]:
+        want = refio.read_bytes(os.path.join(gc.GOLDEN, case, run_name, fn))
+        got_path = work / fn
+        assert got_path.exists(), f"{fn} missing; stderr: {pr.stderr[-1500:]}"
+        assert got_path.read_bytes() == want, f"{case}/{run_name}/{fn} differs"
+    order_dependent = any(o in run["opts"] for o in ("-R", "-B", "-V", "-r"))
+    assert ("exchange (files)" in pr.stderr) == (not order_dependent), pr.stderr[-1500:]
+
+
+@pytest.fixture(scope="module")
+def big_case(tmp_path_factory):
+    """a table and a 600 k-read BAM with sequence, big enough for many shares and chunks"""
+    d = tmp_path_factory.mktemp("multi")
+    chroms = [("chr1", 60_000_000), ("chr2", 35_000_000), ("chrM", 16_569)]
+    t = synth.make_table(81, chroms, 80_000, n_names=500, n_fams=30, n_clas=10, overlap_frac=0.05, shuffle_frac=0.02)
+    synth.write_sizes(str(d / "chrom.sizes"), chroms)
+    synth.write_sizes(str(d / "rep.sizes"), t.rep_len.items())
+    synth.write_rmsk(str(d / "rmsk.txt"), t)
+    mk = os.path.join(os.path.dirname(build.HERE), "tools", "mkbam")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", mk, os.path.join(os.path.dirname(build.HERE), "tools", "mkbam.c"), "-lz", "-ldl"])
+    for name, n, seed, xa in (("a.bam", 600_000, 5, 0), ("b.bam", 250_000, 6, 0), ("c.bam", 90_000, 7, 0), ("xa.bam", 300_000, 8, 400)):
+        subprocess.check_call([mk, str(d / "chrom.sizes"), str(n), str(d / name), "60", str(seed), str(xa)])
+    return d
+
+
+def _run(exe, head, d, aln, out, env):
+    os.makedirs(out, exist_ok=True)
+    pr = subprocess.run([exe] + head + ["-o", "out", str(d / "chrom.sizes"), str(d / "rep.sizes"), str(d / "rmsk.txt"), aln], cwd=out, capture_output=True,
+                        text=True, timeout=600, env=env)
+    assert pr.returncode == 0, pr.stderr[-2500:]
+    return pr
+
+
+def _same_dir(a, b):
+    names = sorted(os.listdir(a))
+    assert names and names == sorted(os.listdir(b))
+    for fn in names:
+        assert filecmp.cmp(os.path.join(a, fn), os.path.join(b, fn), shallow=False), fn
+
+
+@pytest.mark.parametrize("head", [["stat", "-w"], ["filter", "-n", "Rep3"], ["stat", "-w", "-E", "0", "-Q", "30"]])
+def test_shares_of_one_file_and_of_a_file_list(head, exe, big_case):
+    """2, 3 and 4 ranks over ONE file and over a LIST of three files of different sizes (shares then start and end inside
+    different files, some ranks get pieces of two files): same files as the one-rank run, whatever the chunking."""
+    d = big_case
+    tag = "_".join(head).replace("-", "")
+    lst = ",".join(str(d / n) for n in ("a.bam", "b.bam", "c.bam"))
+    for aln, what in ((str(d / "a.bam"), "one"), (lst, "list")):
+        if head[0] == "filter" and what == "list":
+            continue                                                     # filter takes one file
+        ref_dir = str(d / f"ref_{tag}_{what}")
+        _run(exe, head, d, aln, ref_dir, dict(os.environ))
+        for n, chunk in ((2, None), (3, "300000"), (4, "90000")):
+            out = str(d / f"r{n}_{tag}_{what}")
+            pr = _run(exe, head, d, aln, out, _ranks_env(n, **({"ITX_BGZF_CHUNK": chunk} if chunk else {})))
+            assert "exchange (files)" in pr.stderr and "share boundary" not in pr.stderr, pr.stderr[-1500:]
+            _same_dir(ref_dir, out)
+
+
+def test_xa_veto_shards_by_record(exe, big_case):
+    """The XA veto looks at one record and the table, nothing else: it shards like the rest (its counter travels with the
+    partial). A BAM with XA tags on 40 % of the reads, 3 ranks vs one."""
+    d = big_case
+    ref_dir, out = str(d / "xa_ref"), str(d / "xa_r3")
+    _run(exe, ["stat", "-w"], d, str(d / "xa.bam"), ref_dir, dict(os.environ))
+    pr = _run(exe, ["stat", "-w"], d, str(d / "xa.bam"), out, _ranks_env(3, ITX_BGZF_CHUNK="200000"))
+    assert "exchange (files)" in pr.stderr
+    _same_dir(ref_dir, out)
+    rep = open(os.path.join(out, "out.iteres.report")).read()
+    assert "different subfamilies: 0" not in rep                           # the veto did fire
+
+
+def test_ranks_started_by_a_launcher(exe, big_case):
+    """What bench.py does under torch.distributed.run: the ranks are separate processes somebody else started, told who
+    they are through ITX_RANK / ITX_WORLD / ITX_DEVICE / ITX_COMM_ID / ITX_EXCHANGE; rank 0 writes the files."""
+    d = big_case
+    ref_dir = str(d / "launch_ref")
+    _run(exe, ["stat", "-w"], d, str(d / "a.bam"), ref_dir, dict(os.environ))
+    world = 3
+    procs = []
+    for r in range(world):
+        out = str(d / f"launch_rank{r}")
+        os.makedirs(out, exist_ok=True)
+        env = dict(os.environ, ITX_RANK=str(r), ITX_WORLD=str(world), ITX_DEVICE="0", ITX_COMM_ID=str(d / "launch.id"), ITX_EXCHANGE="file", ITX_SPLIT_MIN="1",
+                   ITX_COMM_TIMEOUT="120")
+        procs.append(subprocess.Popen([exe, "stat", "-w", "-o", "out", str(d / "chrom.sizes"), str(d / "rep.sizes"), str(d / "rmsk.txt"), str(d / "a.bam")], cwd=out,
+                                      env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    errs = [p.communicate(timeout=600)[1] for p in procs]
+    assert all(p.returncode == 0 for p in procs), errs
+    _same_dir(ref_dir, str(d / "launch_rank0"))
+    for r in range(1, world):
+        assert os.listdir(str(d / f"launch_rank{r}")) == []                 # only rank 0 writes
+        assert errs[r] == ""                                                  # and only rank 0 talks
+
+
+def test_false_split_point_falls_back_to_one_rank(exe, tmp_path):
+    """A split point is a guess (8 well-formed records in a row). Here every record carries, inside a byte-array tag, forty
+    well-formed DECOY records — nine tenths of the file are decoys, and BGZF blocks start inside them: the guesses land on
+    decoys (tests/test_host_reader.py shows it for this very file), the rank before finds that its record chain does not
+    arrive there, and the job is done again by one rank — same files."""
+    chroms = [("c1", 3_000_000)]
+    t = synth.make_table(91, chroms, 4_000, n_names=60, n_fams=10, n_clas=4)
+    synth.write_sizes(str(tmp_path / "chrom.sizes"), chroms)
+    synth.write_sizes(str(tmp_path / "rep.sizes"), t.rep_len.items())
+    synth.write_rmsk(str(tmp_path / "rmsk.txt"), t)
+    r = synth.make_reads(92, chroms, 12_000, read_len=(30, 60))
+    fake = struct.pack("<iiiIIiiii", 40, 0, 5, 2 | (30 << 8), 0, 0, -1, -1, 0) + b"a\0" + bytes(6)
+    decoy = (fake * 40 + struct.pack("<i", 33) + bytes(range(40, 80))).hex()
+    r.aux = [[f"ZZ:B:{decoy}"] for _ in range(len(r))]
+    bam = str(tmp_path / "decoy.bam")
+    synth.write_bam(bam, r, with_seq=True)
+
+    class D:                                                               # _run takes a directory-like with the three tables
+        def __truediv__(self, n):
+            return tmp_path / n
+    ref_dir, out = str(tmp_path / "ref"), str(tmp_path / "r4")
+    _run(exe, ["stat", "-w"], D(), bam, ref_dir, dict(os.environ))
+    pr = _run(exe, ["stat", "-w"], D(), bam, out, _ranks_env(4))
+    assert "share boundary was not a record start" in pr.stderr, pr.stderr[-1500:]
+    _same_dir(ref_dir, out)
+
+
+def test_rccl_bring_up_with_one_rank(tmp_path):
+    """RCCL refuses two ranks on one GPU, so on a one-GPU box the ncclReduce path can only be walked with ONE rank
+    (ITX_COMM_SELFTEST): library loaded, entry points found, id handed over through the file, communicator made, both
+    reduces and the host vector through it — the buffers must come back unchanged."""
+    import ctypes as C
+    import torch
+    L = eng.load()
+    os.environ["ITX_COMM_SELFTEST"] = "1"
+    try:
+        h = C.c_void_p()
+        rc = L.itx_comm_create(0, 1, 0, str(tmp_path / "self.id").encode(), 0, C.byref(h))
+        assert rc == 0, L.itx_last_error()
+        a = torch.arange(1, 100_001, dtype=torch.int64, device="cuda:0")
+        b = torch.arange(7, 300_007, dtype=torch.int32, device="cuda:0")
+        meta = np.array([5, 6, 7, 8], np.uint64)
+        torch.cuda.synchronize()
+        rc = L.itx_comm_reduce_sum(h, a.data_ptr(), a.numel(), b.data_ptr(), b.numel(), meta.ctypes.data_as(C.c_void_p), 4, None)
+        assert rc == 0, L.itx_last_error()
+        assert int(a.sum()) == 100_000 * 100_001 // 2 and int(b[0]) == 7 and int(b[-1]) == 300_006
+        assert list(meta) == [5, 6, 7, 8]
+        L.itx_comm_destroy(h)
+    finally:
+        os.environ.pop("ITX_COMM_SELFTEST", None)

@@ -133,3 +133,82 @@ def test_many_small_blocks_and_truncation(dump, tmp_path):
     open(bad, "wb").write(b"this is not a bam file" * 10)
     pr = subprocess.run([dump, bad, "0"], capture_output=True, text=True)
     assert pr.returncode == 1
+
+
+# ---- split points of the multi-GPU shares (bamio.c: find_split) --------------------------------------------------------
+@pytest.fixture(scope="module")
+def split_dump(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bin") / "split_dump")
+    subprocess.check_call(["gcc", "-O2", "-g", "-fopenmp", "-std=gnu11", "-o", exe, os.path.join(HOST, "test", "split_dump.c"),
+                           os.path.join(HOST, "bamio.c"), os.path.join(HOST, "tables.c"), "-lz", "-ldl"])
+    return exe
+
+
+def _record_starts(path):
+    """(blocks of the file, set of inflated offsets at which a record starts) by an independent walk"""
+    import struct
+    import zlib
+    comp = open(path, "rb").read()
+    blocks = eng.index_bgzf(comp)
+    u = b"".join(zlib.decompress(comp[int(b["coff"]) + 18:int(b["coff"]) + int(b["csize"]) - 8], -15) for b in blocks)
+    p = 4
+    lt = struct.unpack_from("<i", u, p)[0]
+    p += 4 + lt
+    nref = struct.unpack_from("<i", u, p)[0]
+    p += 4
+    for _ in range(nref):
+        ln = struct.unpack_from("<i", u, p)[0]
+        p += 4 + ln + 4
+    starts = set()
+    while p + 4 <= len(u):
+        starts.add(p)
+        p += 4 + struct.unpack_from("<i", u, p)[0]
+    return comp, blocks, starts
+
+
+def _splits(exe, path, ats):
+    out = subprocess.run([exe, path] + [str(a) for a in ats], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return [tuple(int(x) for x in ln.split()) for ln in out.stdout.strip().split("\n")]
+
+
+def test_split_points_are_record_starts(split_dump, tmp_path):
+    """Where a rank's share of a BAM begins: for compressed offsets all over an ordinary file (short reads, a few long
+    ones, blocks that start inside records) the point find_split gives is a block of the file, inside that block, at or
+    after the offset asked for, and a true record start; offsets near the end give none."""
+    chroms = [("c1", 30_000_000), ("c2", 8_000_000)]
+    r = synth.make_reads(201, chroms, 60_000, read_len=(30, 160), paired_frac=0.2)
+    path = str(tmp_path / "plain.bam")
+    synth.write_bam(path, r, with_seq=True)
+    comp, blocks, starts = _record_starts(path)
+    uoff = {int(b["coff"]): (int(b["uoff"]), int(b["usize"]), int(b["csize"])) for b in blocks}
+    rng = np.random.default_rng(3)
+    ats = sorted(set([1, 100, len(comp) // 2, len(comp) - 29, len(comp) - 1] + [int(x) for x in rng.integers(1, len(comp), 60)]))
+    found = 0
+    for at, f, b, o, cs in _splits(split_dump, path, ats):
+        if f == 0:
+            assert at > int(blocks["coff"][-3])                      # only behind the last blocks that hold records
+            continue
+        assert f == 1 and b in uoff and b >= at and o < uoff[b][1] and cs == uoff[b][2]
+        assert uoff[b][0] + o in starts, (at, b, o)
+        found += 1
+    assert found > 50
+
+
+def test_split_points_can_be_fooled_by_decoys(split_dump, tmp_path):
+    """The guess is only a guess: in a file that is nine tenths well-formed DECOY records (inside byte-array tags), the
+    split points land on decoys — which is why the rank whose share ends there verifies the point, and why the job falls
+    back to one rank when it does not hold (tests/test_cli_multi.py runs this very file through the command)."""
+    import struct
+    chroms = [("c1", 3_000_000)]
+    r = synth.make_reads(92, chroms, 12_000, read_len=(30, 60))
+    fake = struct.pack("<iiiIIiiii", 40, 0, 5, 2 | (30 << 8), 0, 0, -1, -1, 0) + b"a\0" + bytes(6)
+    decoy = (fake * 40 + struct.pack("<i", 33) + bytes(range(40, 80))).hex()
+    r.aux = [[f"ZZ:B:{decoy}"] for _ in range(len(r))]
+    path = str(tmp_path / "decoy.bam")
+    synth.write_bam(path, r, with_seq=True)
+    comp, blocks, starts = _record_starts(path)
+    uoff = {int(b["coff"]): int(b["uoff"]) for b in blocks}
+    res = _splits(split_dump, path, [len(comp) * k // 4 for k in (1, 2, 3)])
+    assert all(f == 1 for _, f, _, _, _ in res)
+    assert any(uoff[b] + o not in starts for _, _, b, o, _ in res)

@@ -75,6 +75,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 __device__ __forceinline__ uint32_t top_entry(uint32_t bsx, uint32_t bsx_hi, bool wide, int32_t qe, int32_t shift, uint32_t bin_lo, uint32_t lo_w)
 {
     const uint32_t b = (((uint32_t)qe >> shift) - bin_lo + 1u) & 127u;
+
     uint32_t h1 = (uint32_t)__shfl((int32_t)bsx, (int)(b & 63u), 64);
     if (wide) {                                                    // wave-uniform
         const uint32_t h2 = (uint32_t)__shfl((int32_t)bsx_hi, (int)(b & 63u), 64);
@@ -183,8 +184,10 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
 #ifdef ITX_ABLATE
     uint32_t sink = 0;      // timing-only builds: stop the tile early, keep what was computed alive
 #define ITX_ABLATE_AT(k, expr) if (ITX_ABLATE == (k)) { sink += (expr); continue; }
+#define ITX_ABLATE_NOT(k) (ITX_ABLATE != (k))     // timing-only builds that leave ONE piece out (6: partition counts, 7: key stores)
 #else
 #define ITX_ABLATE_AT(k, expr)
+#define ITX_ABLATE_NOT(k) true
 #endif
 
     for (size_t tb = begin + (size_t)w * WTILE; tb < end; tb += (size_t)(SB / 64) * WTILE) {
@@ -198,11 +201,22 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         bool tile_pe = have_pe;                                                 // wave-uniform: mate fields were read
         if (full) {
 #if RPL == 4
+#ifndef ITX_NO_NT
+            // the records go by once: streaming loads leave the caches to the table (measured: 1 % at 500 M records)
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i t4v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(B.tid + r0));
+            const v4i p4v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(B.pos + r0));
+            const v4i e4v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(B.tmpend + r0));
+            const int4 t4 = make_int4(t4v.x, t4v.y, t4v.z, t4v.w), p4 = make_int4(p4v.x, p4v.y, p4v.z, p4v.w), e4 = make_int4(e4v.x, e4v.y, e4v.z, e4v.w);
+            const uint32_t mq = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(B.mapq + r0));
+            const uint32_t f4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(B.flag5 + r0));
+#else
             const int4 t4 = *reinterpret_cast<const int4 *>(B.tid + r0);
             const int4 p4 = *reinterpret_cast<const int4 *>(B.pos + r0);
             const int4 e4 = *reinterpret_cast<const int4 *>(B.tmpend + r0);
             const uint32_t mq = *reinterpret_cast<const uint32_t *>(B.mapq + r0);
             const uint32_t f4 = *reinterpret_cast<const uint32_t *>(B.flag5 + r0);
+#endif
             raw[0] = {t4.x, p4.x, e4.x, mq & 0xffu, f4 & 0x3fu};
             raw[1] = {t4.y, p4.y, e4.y, (mq >> 8) & 0xffu, (f4 >> 8) & 0x3fu};
             raw[2] = {t4.z, p4.z, e4.z, (mq >> 16) & 0xffu, (f4 >> 16) & 0x3fu};
@@ -382,12 +396,32 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                     // so records that are done just keep stepping, count nothing, and come to rest on the sentinel.
                     uint32_t kk[RPL], hk[RPL];        // hk: window entries of the hits so far, one byte each, newest lowest
                     uint32_t f_rk[RPL];               // FIRST: smallest list-order rank among the hits so far (hk = its entry)
+#ifdef ITX_SMALL_SLICE
+                    if (nb <= 4) {
+                        // dense read sets: the tile spans a handful of bins and the slice's entries are wave-uniform values —
+                        // three lane reads (scalar registers) and three selects per record instead of a trip through the LDS
+                        // crossbar (ds_bpermute) that the scan would have to wait for
+                        const uint32_t e1 = __builtin_elementwise_sub_sat((uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, 1), lo_w);
+                        const uint32_t e2 = __builtin_elementwise_sub_sat((uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, 2), lo_w);
+                        const uint32_t e3 = __builtin_elementwise_sub_sat((uint32_t)__builtin_amdgcn_readlane((int32_t)bs.x, 3), lo_w);
+#pragma unroll
+                        for (int j = 0; j < RPL; j++) {
+                            const uint32_t b = ((uint32_t)qe[j] >> T.shift) - bin_lo + 1u;         // 1 .. nb - 1 for a record that goes on
+                            const uint32_t top = b == 1u ? e1 : b == 2u ? e2 : e3;
+                            kk[j] = q[j] ? top : 0u;
+                            hk[j] = 0;
+                            f_rk[j] = 0xffffffffu;
+                        }
+                    } else
+#endif
+                    {
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
                         const uint32_t top = top_entry(bs.x, bsx_hi, wide, qe[j], T.shift, bin_lo, lo_w);   // a shuffle: every lane takes part
                         kk[j] = q[j] ? top : 0u;                  // rows [0, top) <=> entries [1, top]
                         hk[j] = 0;
                         f_rk[j] = 0xffffffffu;
+                    }
                     }
                     bool any;
                     do {
@@ -581,13 +615,13 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 const uint32_t u = uq[j] ? 4u : 0u;
                 const uint32_t lo = (hB[j] && !two[j]) ? (((sB[j] - sA[j]) << 3) | u) : (1u | u);
                 if (hit[j] >= 0) {
-                    w_out[at] = make_uint2(lo, sA[j]);
-                    atomicAdd(&s_pc[sA[j] >> E.log_w], 1u);                      // keys per partition of this workgroup's region
+                    if (ITX_ABLATE_NOT(7)) w_out[at] = make_uint2(lo, sA[j]);
+                    if (ITX_ABLATE_NOT(6)) atomicAdd(&s_pc[sA[j] >> E.log_w], 1u);   // keys per partition of this workgroup's region
                 }
                 at += hit[j] >= 0 ? 1u : 0u;
                 if (two[j]) {
-                    w_out[at] = make_uint2(2u | u, sB[j]);
-                    atomicAdd(&s_pc[sB[j] >> E.log_w], 1u);
+                    if (ITX_ABLATE_NOT(7)) w_out[at] = make_uint2(2u | u, sB[j]);
+                    if (ITX_ABLATE_NOT(6)) atomicAdd(&s_pc[sB[j] >> E.log_w], 1u);
                 }
                 at += two[j] ? 1u : 0u;
             }

@@ -243,7 +243,7 @@ int itx_engine_get_stats(itx_engine *e, itx_stats *out);
  * i inflated to exactly usize bytes, else a small positive code (the data is damaged or the decoder declined it —
  * the caller's zlib has the last word, as in the reference). Synchronous; one calling thread per inflater. */
 typedef struct itx_inflater itx_inflater;
-#define ITX_BAMWIN_LANES 2        /* pushes that may be in flight at once (push_begin's s) */
+#define ITX_BAMWIN_LANES 4        /* pushes that may be in flight at once (push_begin's s) */
 #define ITX_BAMWIN_WINDOWS 48     /* windows of inflated bytes (w): the decode may run this far ahead of the consumer (a window's
                                    * buffer is allocated when it is first pushed into: 288 GB of HBM is room for a long lead) */
 typedef struct itx_bgzf_block {
@@ -278,6 +278,12 @@ int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve
  * Records are located by guess-and-verify (csrc/itx_inflate.hip): exact whatever the bytes look like. A record of
  * more than 4 MiB that straddles two chunks is beyond this path (ITX_E_LIMIT). One thread may push while another
  * parses / fetches the OTHER window. */
+/* Before a stream of pushes, while the device is idle: every buffer the pushes will need, sized for chunks of at most
+ * comp_bytes compressed bytes / max_blocks blocks / max_bytes inflated bytes, so that nothing is allocated (and, worse,
+ * freed: hipFree waits for every kernel in flight) inside the pipeline — ONE device allocation for all of it. *n_windows,
+ * in: the most the caller can use (< 1: no preference); out: how many windows were set up (w < *n_windows; between 4 and
+ * ITX_BAMWIN_WINDOWS, by what the device has free). Optional: without it the buffers grow on demand. */
+int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t max_blocks, size_t max_bytes, int *n_windows);
 int itx_bamwin_push(itx_inflater *h, int w, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, uint8_t *status, size_t *n_new);
 /* push in two halves, for a caller that keeps several pushes going (s < ITX_BAMWIN_LANES: each has its own stream and scratch,
  * so the latency-bound Huffman pass of one chunk runs beside the replay of the previous ones): begin enqueues and returns;

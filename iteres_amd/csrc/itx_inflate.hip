@@ -22,6 +22,14 @@ static __device__ inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
 }
 #define ITXI_PKSIGN16(a, b) itxi_pksign16(a, b)
 #define ITXI_LOADW(w, i) ((w)[(i)])
+#define ITXI_LOAD4(WORDS, AT, R0, R1, R2, R3)                                    \
+    do {                                                                         \
+        const uint4 v4__ = *reinterpret_cast<const uint4 *>((WORDS) + (AT));     \
+        (R0) = v4__.x;                                                           \
+        (R1) = v4__.y;                                                           \
+        (R2) = v4__.z;                                                           \
+        (R3) = v4__.w;                                                           \
+    } while (0)
 #define ITXI_LOADB(p, i) ((p)[(i)])
 // A far match reads bytes this wave stored earlier through other lanes. Workgroup scope is all it takes — the wave's
 // stores have to be acknowledged before its loads go out (s_waitcnt vmcnt(0)); the lines read are whole stripes written
@@ -29,8 +37,10 @@ static __device__ inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
 #define ITXI_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 #include "itx_inflate_core.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define BGZF_HEADER 18u      /* gzip header with the one "BC" extra field (bgzf.c:401-411) */
 #define BGZF_TRAILER 8u      /* CRC32 + ISIZE */
@@ -69,6 +79,31 @@ __global__ __launch_bounds__(64) void k_resolve(const itx_bgzf_block *__restrict
         rc = itxi_resolve(s_ring, s_stage, lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, meta[3 * b + 1], meta[3 * b + 2], out, blk[b].uoff, blk[b].usize,
                           threadIdx.x);
     if (threadIdx.x == 0) status[b] = (uint8_t)rc;
+}
+
+// pass 2 as the pushes run it: a fixed set of waves that take blocks off a counter. ONE workgroup of RES_WAVES waves per
+// CU, holding RES_WAVES x 6 KB of LDS — which leaves a CU room for one pass-1 workgroup (68 KB) beside it. Launched one
+// wave per block instead, pass 2 keeps every CU's LDS full of its own 6-KB workgroups, a 68-KB hole never opens, and the
+// pass 1 of the next chunk only starts when the pass 2 of this one has drained: the two passes of different chunks, which
+// are both latency-bound and want to run side by side, took turns (measured: a chunk every 21 ms with two pushes in flight,
+// the sum of its two passes).
+#define RES_WAVES 14u
+__global__ __launch_bounds__(RES_WAVES * 64u) void k_resolve_p(const itx_bgzf_block *__restrict__ blk, uint32_t n, const uint8_t *__restrict__ lit,
+                                                               const uint32_t *__restrict__ tok, const uint32_t *__restrict__ meta, uint8_t *__restrict__ out,
+                                                               uint8_t *__restrict__ status, uint32_t *__restrict__ next)
+{
+    __shared__ uint32_t s_ring[RES_WAVES][ITXI_RING / 4], s_stage[RES_WAVES][ITXI_LSTAGE / 4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    (void)next;
+    const uint32_t stride = gridDim.x * RES_WAVES;
+    // blocks dealt to the waves in turn (they cost about the same: BGZF blocks are cut by size)
+    for (uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(blockIdx.x * RES_WAVES + wv)); b < n; b += stride) {
+        int rc = (int)meta[3 * b];
+        if (rc == ITXI_OK)
+            rc = itxi_resolve(s_ring[wv], s_stage[wv], lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, meta[3 * b + 1], meta[3 * b + 2], out, blk[b].uoff,
+                              blk[b].usize, lane);
+        if (lane == 0) status[b] = (uint8_t)rc;
+    }
 }
 
 // =====================================================================================================================
@@ -268,9 +303,15 @@ __global__ void k_warm(uint32_t *p)
     if (p) *p = 0;
 }
 
+static void report_at_exit();
+
 struct itx_inflater {
     int device;
     hipStream_t st[2];
+    hipStream_t st_res;                    // every push's pass 2, one after the other (see k_resolve_p)
+    uint8_t *arena;                        // itx_inflater_reserve: the one allocation the lanes' and the first n_reserved_win windows' buffers are cut from
+    int n_reserved_win;
+    int n_cu;
     uint8_t *d_comp, *d_out, *d_status, *d_lit;
     uint32_t *d_tok, *d_meta;
     itx_bgzf_block *d_blk;
@@ -287,6 +328,9 @@ struct itx_inflater {
     struct {
         hipStream_t st;
         hipEvent_t copied;                 // the compressed bytes have left the caller's buffer
+        hipEvent_t ev[3];                  // ITX_TIMING: before pass 1, between the passes, after pass 2
+        hipEvent_t p1_done, done;          // pass 1 through (the shared pass-2 stream waits for it); the whole push through
+        uint32_t *d_next;                  // pass 2's block counter
         uint8_t *d_comp, *d_status, *d_lit, *h_status;
         uint32_t *d_tok, *d_meta;
         itx_bgzf_block *d_blk, *h_blk;     // h_blk (page-locked): the block list shifted to the window's offsets
@@ -327,6 +371,20 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
         INF_HIP(hipStreamCreateWithFlags(&h->lane[k].st, hipStreamNonBlocking));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].copied, hipEventDisableTiming));
+        for (int q = 0; q < 3; q++) INF_HIP(hipEventCreate(&h->lane[k].ev[q]));
+        INF_HIP(hipEventCreateWithFlags(&h->lane[k].p1_done, hipEventDisableTiming));
+        INF_HIP(hipEventCreateWithFlags(&h->lane[k].done, hipEventDisableTiming));
+        INF_HIP(hipMalloc((void **)&h->lane[k].d_next, 16));
+    }
+    INF_HIP(hipStreamCreateWithFlags(&h->st_res, hipStreamNonBlocking));
+    h->n_cu = 256;
+    if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
+    if (getenv("ITX_TIMING")) {
+        static bool once;
+        if (!once) {
+            once = true;
+            atexit(report_at_exit);
+        }
     }
     hipLaunchKernelGGL(k_warm, dim3(1), dim3(1), 0, h->st[0], (uint32_t *)nullptr);
     INF_HIP(hipGetLastError());
@@ -351,22 +409,34 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_lit);
     (void)hipFree(h->d_tok);
     (void)hipFree(h->d_meta);
-    for (int k = 0; k < ITX_BAMWIN_WINDOWS; k++) (void)hipFree(h->win[k].buf);
+    for (int k = h->arena ? h->n_reserved_win : 0; k < ITX_BAMWIN_WINDOWS; k++) (void)hipFree(h->win[k].buf);
+    if (h->st_res) {
+        (void)hipStreamSynchronize(h->st_res);
+        (void)hipStreamDestroy(h->st_res);
+    }
     for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
         if (h->lane[k].st) {
             (void)hipStreamSynchronize(h->lane[k].st);
             (void)hipStreamDestroy(h->lane[k].st);
         }
         if (h->lane[k].copied) (void)hipEventDestroy(h->lane[k].copied);
-        (void)hipFree(h->lane[k].d_comp);
-        (void)hipFree(h->lane[k].d_status);
-        (void)hipFree(h->lane[k].d_lit);
-        (void)hipFree(h->lane[k].d_tok);
-        (void)hipFree(h->lane[k].d_meta);
-        (void)hipFree(h->lane[k].d_blk);
+        for (int q = 0; q < 3; q++)
+            if (h->lane[k].ev[q]) (void)hipEventDestroy(h->lane[k].ev[q]);
+        if (h->lane[k].p1_done) (void)hipEventDestroy(h->lane[k].p1_done);
+        if (h->lane[k].done) (void)hipEventDestroy(h->lane[k].done);
+        (void)hipFree(h->lane[k].d_next);
+        if (!h->arena) {
+            (void)hipFree(h->lane[k].d_comp);
+            (void)hipFree(h->lane[k].d_status);
+            (void)hipFree(h->lane[k].d_lit);
+            (void)hipFree(h->lane[k].d_tok);
+            (void)hipFree(h->lane[k].d_meta);
+            (void)hipFree(h->lane[k].d_blk);
+        }
         if (h->lane[k].h_blk) (void)hipHostFree(h->lane[k].h_blk);
         if (h->lane[k].h_status) (void)hipHostFree(h->lane[k].h_status);
     }
+    (void)hipFree(h->arena);
     (void)hipFree(h->d_sum);
     (void)hipFree(h->d_spec);
     (void)hipFree(h->d_pb);
@@ -400,14 +470,40 @@ extern "C" void itx_pinned_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
-template <typename T> static int grow(T **p, size_t *cap, size_t need)
+// ITX_TIMING: where the decoder's device-side time goes (printed when the process ends)
+static double g_alloc_s, g_tok_ms, g_res_ms;
+static unsigned long g_allocs, g_pushes;
+static double wall_now()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void report_at_exit()
+{
+    fprintf(stderr, "[itx timing] device decoder: %lu pushes, pass 1 %.1f ms and pass 2 %.1f ms per push (HIP events, pushes overlap), %lu device allocations %.3f s\n", g_pushes,
+            g_pushes ? g_tok_ms / (double)g_pushes : 0.0, g_pushes ? g_res_ms / (double)g_pushes : 0.0, g_allocs, g_alloc_s);
+}
+
+template <typename T> static int grow(T **p, size_t *cap, size_t need, bool exact = false)
 {
     if (need <= *cap) return ITX_OK;
+    const double t_alloc0 = wall_now();
+    struct Acc {
+        double t0;
+        ~Acc()
+        {
+            g_alloc_s += wall_now() - t0;
+            g_allocs++;
+        }
+    } acc{t_alloc0};
     if (*p) INF_HIP(hipFree(*p));
     *p = nullptr;
     *cap = 0;
-    const size_t want = need + need / 4;
+    const size_t want = exact ? need : need + need / 4;
+    const double tm0 = wall_now();
     INF_HIP(hipMalloc((void **)p, want * sizeof(T)));
+    if (getenv("ITX_TIMING_ALLOC")) fprintf(stderr, "[itx alloc] hipMalloc %.1f MB: %.2f ms\n", (double)(want * sizeof(T)) / 1e6, 1e3 * (wall_now() - tm0));
     *cap = want;
     return ITX_OK;
 }
@@ -509,6 +605,10 @@ extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *
     if (rc != ITX_OK) return rc;
     if (comp_len > 0xfffffff0u || total + WIN_HEAD > 0xfffffff0u || n_blk > 0x7fffffffu) return ITX_E_LIMIT;
     INF_HIP(hipSetDevice(h->device));
+    if (h->arena && (w >= h->n_reserved_win || WIN_HEAD + total + 64 > h->win[w].cap || comp_len + 64 > Ln.comp_cap || n_blk > Ln.status_cap)) {
+        itx_set_error("push of %zu blocks / %zu bytes into window %d exceeds what itx_inflater_reserve set up", n_blk, total, w);
+        return ITX_E_LIMIT;
+    }
     if ((rc = grow(&h->win[w].buf, &h->win[w].cap, WIN_HEAD + total + 64)) != ITX_OK) return rc;
     h->win[w].start = h->win[w].consumed = WIN_HEAD;
     h->win[w].len = WIN_HEAD + (uint32_t)total;
@@ -541,11 +641,30 @@ extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *
     INF_HIP(hipMemcpyAsync(Ln.d_blk, Ln.h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, st));
     INF_HIP(hipMemcpyAsync(Ln.d_comp, comp, comp_len, hipMemcpyHostToDevice, st));
     INF_HIP(hipEventRecord(Ln.copied, st));
+    INF_HIP(hipEventRecord(Ln.ev[0], st));
     hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta);
     INF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, st, Ln.d_blk, 0u, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta, h->win[w].buf, Ln.d_status);
+    // pass 2: by default on the push's own stream, one wave per block (scratch experiments: ITX_RES_SHARED=1 runs every push's
+    // pass 2 on one shared stream, ITX_RES_PERSIST=1 with a fixed set of waves — neither paid)
+    static const int res_shared = getenv("ITX_RES_SHARED") != nullptr, res_persist = getenv("ITX_RES_PERSIST") != nullptr;
+    hipStream_t sr = st;
+    if (res_shared || res_persist) {
+        sr = h->st_res;
+        INF_HIP(hipEventRecord(Ln.p1_done, st));
+        INF_HIP(hipStreamWaitEvent(sr, Ln.p1_done, 0));
+    }
+    INF_HIP(hipEventRecord(Ln.ev[1], sr));
+    if (res_persist) {
+        const unsigned res_wgs = (unsigned)((n_blk + RES_WAVES - 1) / RES_WAVES) < (unsigned)h->n_cu ? (unsigned)((n_blk + RES_WAVES - 1) / RES_WAVES) : (unsigned)h->n_cu;
+        hipLaunchKernelGGL(k_resolve_p, dim3(res_wgs), dim3(RES_WAVES * 64u), 0, sr, Ln.d_blk, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta, h->win[w].buf, Ln.d_status,
+                           Ln.d_next);
+    } else {
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, sr, Ln.d_blk, 0u, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta, h->win[w].buf, Ln.d_status);
+    }
     INF_HIP(hipGetLastError());
-    INF_HIP(hipMemcpyAsync(Ln.h_status, Ln.d_status, n_blk, hipMemcpyDeviceToHost, st));
+    INF_HIP(hipEventRecord(Ln.ev[2], sr));
+    INF_HIP(hipMemcpyAsync(Ln.h_status, Ln.d_status, n_blk, hipMemcpyDeviceToHost, sr));
+    INF_HIP(hipEventRecord(Ln.done, sr));
     return ITX_OK;
 }
 
@@ -566,10 +685,88 @@ extern "C" int itx_bamwin_push_end(itx_inflater *h, int s, uint8_t *status, size
     auto &Ln = h->lane[s];
     if (!Ln.busy) return ITX_E_STATE;
     INF_HIP(hipSetDevice(h->device));
-    INF_HIP(hipStreamSynchronize(Ln.st));
+    if (Ln.n_blk) INF_HIP(hipEventSynchronize(Ln.done));
+    else INF_HIP(hipStreamSynchronize(Ln.st));
+    if (Ln.n_blk) {
+        float a = 0, b = 0;
+        if (hipEventElapsedTime(&a, Ln.ev[0], Ln.ev[1]) == hipSuccess && hipEventElapsedTime(&b, Ln.ev[1], Ln.ev[2]) == hipSuccess) {
+            g_tok_ms += a;
+            g_res_ms += b;
+            g_pushes++;
+        }
+    }
     if (Ln.n_blk) memcpy(status, Ln.h_status, Ln.n_blk);
     *n_new = Ln.total;
     Ln.busy = 0;
+    return ITX_OK;
+}
+
+/* Everything a stream of pushes will need, allocated once while the device is idle: growing a buffer in the middle of the
+ * pipeline means hipFree, which waits for every kernel in flight. Per lane: the compressed chunk (comp_bytes), block list,
+ * status, literal and token scratch for max_blocks blocks. Windows: as many of max_bytes (+ the carry-over head) as a share
+ * of the free memory allows, at most ITX_BAMWIN_WINDOWS and at most *n_windows on entry when that is >= 1; on return
+ * *n_windows says how many the caller may use (w < *n_windows). */
+extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t max_blocks, size_t max_bytes, int *n_windows)
+{
+    if (!h || !n_windows || max_blocks == 0 || max_blocks > 0x7fffffffu || max_bytes + WIN_HEAD > 0xfffffff0u) return ITX_E_ARG;
+    if (h->arena) return ITX_E_STATE;
+    INF_HIP(hipSetDevice(h->device));
+    for (int k = 0; k < ITX_BAMWIN_LANES; k++)
+        if (h->lane[k].busy || h->lane[k].d_comp) return ITX_E_STATE;
+    size_t free_b = 0, total_b = 0;
+    INF_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t per = (WIN_HEAD + max_bytes + 64 + 255) & ~(size_t)255;
+    size_t n = (free_b / 5 * 2) / per;                              // two fifths of what is free now
+    if (n > ITX_BAMWIN_WINDOWS) n = ITX_BAMWIN_WINDOWS;
+    if (*n_windows >= 1 && (size_t)*n_windows < n) n = (size_t)*n_windows;       // the caller cannot use more
+    if (const char *e = getenv("ITX_RESERVE_WINDOWS"))
+        if (atol(e) >= 2 && (size_t)atol(e) < n) n = (size_t)atol(e);
+    if (n < 4) n = 4;
+    // ONE allocation for all of it: on some hosts every hipMalloc costs ~15 ms whatever its size (and holds up the other
+    // threads' HIP calls meanwhile) — seventy of them were 1.2 s of a 4 s run
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t sz_comp = al(comp_bytes + 64), sz_status = al(max_blocks), sz_blk = al(max_blocks * sizeof(itx_bgzf_block)), sz_lit = al(max_blocks * (size_t)LIT_STRIDE),
+                 sz_tok = al(max_blocks * (size_t)TOK_STRIDE * 4), sz_meta = al(3 * max_blocks * 4);
+    const size_t lane_bytes = sz_comp + sz_status + sz_blk + sz_lit + sz_tok + sz_meta;
+    const size_t total = lane_bytes * ITX_BAMWIN_LANES + per * n;
+    uint8_t *base = nullptr;
+    const double t0 = wall_now();
+    hipError_t he = hipMalloc((void **)&base, total);
+    g_alloc_s += wall_now() - t0;
+    g_allocs++;
+    if (he != hipSuccess) {
+        itx_set_error("itx_inflater_reserve: hipMalloc(%zu) failed: %s", total, hipGetErrorString(he));
+        return ITX_E_NOMEM;
+    }
+    h->arena = base;
+    h->n_reserved_win = (int)n;
+    uint8_t *p = base;
+    for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
+        auto &Ln = h->lane[k];
+        Ln.d_comp = p; p += sz_comp; Ln.comp_cap = comp_bytes + 64;
+        Ln.d_status = p; p += sz_status; Ln.status_cap = max_blocks;
+        Ln.d_blk = (itx_bgzf_block *)p; p += sz_blk; Ln.blk_cap = max_blocks;
+        Ln.d_lit = p; p += sz_lit; Ln.lit_cap = max_blocks * (size_t)LIT_STRIDE;
+        Ln.d_tok = (uint32_t *)p; p += sz_tok; Ln.tok_cap = max_blocks * (size_t)TOK_STRIDE;
+        Ln.d_meta = (uint32_t *)p; p += sz_meta; Ln.meta_cap = 3 * max_blocks;
+        if (Ln.h_cap < max_blocks) {
+            if (Ln.h_blk) (void)hipHostFree(Ln.h_blk);
+            if (Ln.h_status) (void)hipHostFree(Ln.h_status);
+            Ln.h_blk = nullptr;
+            Ln.h_status = nullptr;
+            Ln.h_cap = 0;
+            INF_HIP(hipHostMalloc((void **)&Ln.h_blk, (max_blocks + 64) * sizeof(itx_bgzf_block), hipHostMallocDefault));
+            INF_HIP(hipHostMalloc((void **)&Ln.h_status, max_blocks + 64, hipHostMallocDefault));
+            Ln.h_cap = max_blocks + 64;
+        }
+    }
+    for (size_t w = 0; w < n; w++) {
+        if (h->win[w].buf) (void)hipFree(h->win[w].buf);
+        h->win[w].buf = p;
+        h->win[w].cap = per;
+        p += per;
+    }
+    *n_windows = (int)n;
     return ITX_OK;
 }
 

@@ -37,7 +37,11 @@
 #error "define the ITXI_* hooks before including this file"
 #endif
 
-#define ITXI_RING 8192u                    // pass 2: bytes of output kept in LDS; a power of two, a multiple of the stripe
+#ifndef ITXI_RING
+#define ITXI_RING 4096u                    // pass 2: bytes of output kept in LDS; a power of two, a multiple of the stripe. 6 KB of LDS per
+                                           // wave with the literal stage: 26 waves per CU instead of 13 with 8 + 4 KB — pass 2 is a chain of LDS
+                                           // round trips per token, so resident waves are its throughput (measured: 8.5 ms per 8 k blocks, was 13)
+#endif
 #define ITXI_MASK (ITXI_RING - 1u)
 #define ITXI_STRIPE 256u                   // write-back granule: 64 lanes x 4 bytes
 #define ITXI_NEAR (ITXI_RING - 320u)       // matches up to this distance read the ring (a match writes at most 258 bytes ahead)
@@ -73,33 +77,83 @@ struct ItxiCodes {
 };
 
 struct ItxiIn {
-    const uint32_t *w;                     // the compressed buffer as words (4-byte aligned base)
-    uint32_t ip, end;                      // next word to load; byte offset of the first byte past the block's data
-    uint32_t lim;                          // end / 4 + 2: a well-formed block never loads ahead of this word (see itxi_past)
+    const uint32_t *w;                     // the compressed buffer as words (16-byte aligned base)
+    uint32_t ip, end;                      // next word to enter the bit buffer; byte offset of the first byte past the block's data
+    uint32_t lim;                          // end / 4 + 2: a well-formed block never takes a word beyond this one (see itxi_past)
     uint64_t bb;                           // bit buffer, next bit in bit 0
     uint32_t bn;                           // valid bits in bb
-    uint32_t nw;                           // word ip, loaded ahead of its use: the next load is in flight while symbols decode
+    // Read-ahead: the words ip, ip + 1, .. (na of them, a0 first) are in registers, and the four after those (b0..b3, word
+    // index nb) are on their way. A lane that decodes alone on its SIMD cannot hide a load behind other waves: with one word
+    // of look-ahead every match — which takes up to 48 bits, two refills — waited for memory once. With 16 to 32 bytes of
+    // look-ahead (a dozen symbols) the next batch has long arrived when the current one is used up.
+    uint32_t a0, a1, a2, a3, na;
+    uint32_t b0, b1, b2, b3, nb;
+    uint32_t stop;                         // batches at or beyond this word index lie past the block's last 16-byte line: they read as zeros
 };
+
+#ifndef ITXI_LOAD4
+#define ITXI_LOAD4(w, i, a, b, c, d)   \
+    do {                               \
+        (a) = ITXI_LOADW(w, (i));      \
+        (b) = ITXI_LOADW(w, (i) + 1u); \
+        (c) = ITXI_LOADW(w, (i) + 2u); \
+        (d) = ITXI_LOADW(w, (i) + 3u); \
+    } while (0)
+#endif
+
+// the batch of four words at word index i (a multiple of four) into b0..b3; nothing past the block's last 16-byte line is
+// touched: at most 15 bytes beyond `end` are ever read (a BGZF block's 8-byte trailer and the caller's 16 bytes of padding
+// follow it), and what lies further reads as zeros — consuming those is caught by itxi_overrun / itxi_past
+ITXI_FN void itxi_batch(ItxiIn &in, uint32_t i)
+{
+    in.nb = i;
+    in.b0 = in.b1 = in.b2 = in.b3 = 0;
+    if (i < in.stop) ITXI_LOAD4(in.w, i, in.b0, in.b1, in.b2, in.b3);
+}
+
+ITXI_FN uint32_t itxi_take(ItxiIn &in)                      // the word at ip; keeps the read-ahead going
+{
+    const uint32_t w = in.a0;
+    in.a0 = in.a1;
+    in.a1 = in.a2;
+    in.a2 = in.a3;
+    in.na--;
+    if (in.na == 0) {
+        in.a0 = in.b0;
+        in.a1 = in.b1;
+        in.a2 = in.b2;
+        in.a3 = in.b3;
+        in.na = 4;
+        itxi_batch(in, in.nb + 4u);
+    }
+    in.ip++;
+    return w;
+}
 
 ITXI_FN void itxi_in_start(ItxiIn &in, uint32_t byte_pos)
 {
-    in.ip = byte_pos >> 2;
+    in.stop = ((in.end + 15u) & ~15u) >> 2;
+    const uint32_t first = byte_pos >> 2, base = first & ~3u;
+    itxi_batch(in, base);
+    in.a0 = in.b0;
+    in.a1 = in.b1;
+    in.a2 = in.b2;
+    in.a3 = in.b3;
+    in.na = 4;
+    itxi_batch(in, base + 4u);
+    in.ip = base;
+    for (uint32_t k = base; k < first; k++) (void)itxi_take(in);          // the words of the line in front of the data
     const uint32_t skip = (byte_pos & 3u) * 8u;
-    in.bb = (uint64_t)(ITXI_LOADW(in.w, in.ip) >> skip);
-    in.ip++;
+    in.bb = (uint64_t)(itxi_take(in) >> skip);
     in.bn = 32u - skip;
-    in.nw = ITXI_LOADW(in.w, in.ip);
 }
 
-// at least 33 valid bits afterwards; reading a few words past the end is harmless (at most 19 bytes, see itxi_past: the caller pads
-// the buffer by 16 bytes behind the block's 8-byte trailer), consuming them is caught by the callers through itxi_overrun / itxi_past
+// at least 33 valid bits afterwards
 ITXI_FN void itxi_refill(ItxiIn &in)
 {
     if (in.bn <= 32u) {
-        in.bb |= (uint64_t)in.nw << in.bn;
-        in.ip++;
+        in.bb |= (uint64_t)itxi_take(in) << in.bn;
         in.bn += 32u;
-        in.nw = ITXI_LOADW(in.w, in.ip);
     }
 }
 
@@ -117,11 +171,9 @@ ITXI_FN bool itxi_overrun(const ItxiIn &in)                 // a bit of a byte a
     return in.ip * 4u - (in.bn >> 3) > in.end;
 }
 
-// The cheap bound for loops that consume input without producing a reason to stop (a run of literals): the read-ahead has
-// passed the last word a well-formed block can have loaded. A valid block has 4 * ip - bn / 8 <= end with bn <= 64 wherever
-// it is tested, so ip <= end / 4 + 2 = lim there. With the test in place every turn of the symbol loop starts at ip <= lim
-// and refills at most twice before one of the two tests ends it: the highest word ever loaded is lim + 2, i.e. at most 19
-// bytes past `end` — inside what the callers promise (a BGZF block's 8-byte trailer follows `end`, then 16 bytes of padding).
+// The cheap bound for loops that consume input without producing a reason to stop (a run of literals): more words have
+// entered the bit buffer than a well-formed block can have taken. A valid block has 4 * ip - bn / 8 <= end with bn <= 64
+// wherever it is tested, so ip <= end / 4 + 2 = lim there. (What is READ is bounded separately, by itxi_batch.)
 ITXI_FN bool itxi_past(const ItxiIn &in) { return in.ip > in.lim; }
 
 // One symbol of a canonical code: codes of each length are consecutive integers, shorter codes first (RFC 1951 3.2.2), so
@@ -199,9 +251,13 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint
 // What pass 1 leaves for pass 2, per block: lit[0, n_lit) the literal bytes in stream order; tok[0, n_tok) the matches,
 // x = literals since the previous match | length << 16, y = distance; literals after the last match: n_lit - (sum of x's
 // low halves). A stored block's bytes are literals.
+struct __attribute__((aligned(8))) ItxiPair {
+    uint32_t x, y;
+};
+
 struct ItxiTokens {
-    uint8_t *lit;
-    uint32_t *tok;                         // pairs (x, y)
+    uint8_t *lit;                          // 4-byte aligned, with room for 3 bytes past the last literal
+    uint32_t *tok;                         // pairs (x, y), 8-byte aligned
     uint32_t n_lit, n_tok;
 };
 
@@ -216,6 +272,19 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
     itxi_in_start(in, data_pos);
     uint32_t produced = 0;                 // bytes the tokens so far stand for
     uint32_t n_lit = 0, n_tok = 0, run = 0;       // run: literals since the last match
+    // literals leave four at a time (a lane's stores are to its own block's scratch: every store instruction of the wave
+    // touches as many cache lines as it has active lanes, so fewer, wider stores are what counts), matches as one 8-byte pair
+    uint32_t lacc = 0;
+    uint32_t *lit32 = reinterpret_cast<uint32_t *>(K.lit);
+#define ITXI_PUT_LIT(byte)                                   \
+    do {                                                     \
+        lacc |= (uint32_t)(byte) << ((n_lit & 3u) * 8u);     \
+        n_lit++;                                             \
+        if ((n_lit & 3u) == 0) {                             \
+            lit32[(n_lit >> 2) - 1u] = lacc;                 \
+            lacc = 0;                                        \
+        }                                                    \
+    } while (0)
     K.n_lit = K.n_tok = 0;
     ItxiCodes lc, dc;
 
@@ -236,8 +305,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
             if (pos + len > data_end) return ITXI_E_INPUT;
             if (len > usize - produced) return ITXI_E_OUTPUT;
             const uint8_t *src = reinterpret_cast<const uint8_t *>(comp_words) + pos;
-            for (uint32_t k = 0; k < len; k++) K.lit[n_lit + k] = ITXI_LOADB(src, k);
-            n_lit += len;
+            for (uint32_t k = 0; k < len; k++) ITXI_PUT_LIT(ITXI_LOADB(src, k));
             run += len;
             produced += len;
             itxi_in_start(in, pos + len);
@@ -315,8 +383,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (sym < 256u) {
                     if (itxi_past(in)) return ITXI_E_INPUT;       // literals out of the bytes behind the block: stop before the padding ends
                     if (produced >= usize) return ITXI_E_OUTPUT;
-                    K.lit[n_lit] = (uint8_t)sym;
-                    n_lit++;
+                    ITXI_PUT_LIT(sym);
                     run++;
                     produced++;
                     continue;
@@ -342,8 +409,8 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
                 if (dist > produced) return ITXI_E_DIST;
                 if (len > usize - produced) return ITXI_E_OUTPUT;
-                K.tok[2 * n_tok] = run | (len << 16);
-                K.tok[2 * n_tok + 1] = dist;
+                ItxiPair *tp = reinterpret_cast<ItxiPair *>(K.tok) + n_tok;
+                *tp = ItxiPair{run | (len << 16), dist};
                 n_tok++;
                 run = 0;
                 produced += len;
@@ -353,6 +420,8 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
         if (last) break;
     }
     if (produced != usize) return ITXI_E_OUTPUT;
+    if (n_lit & 3u) lit32[n_lit >> 2] = lacc;                      // the scratch has room past the last literal
+#undef ITXI_PUT_LIT
     K.n_lit = n_lit;
     K.n_tok = n_tok;
     return ITXI_OK;
@@ -394,7 +463,9 @@ ITXI_FN void itxi_flush_full(const uint32_t *ring32, ItxiOut &o, uint32_t lane)
     if (full > o.fl) itxi_writeback(ring32, o, full, lane);
 }
 
-#define ITXI_LSTAGE 4096u                  // pass 2: literal bytes staged in LDS per refill (16 bytes per lane and load)
+#ifndef ITXI_LSTAGE
+#define ITXI_LSTAGE 2048u                  // pass 2: literal bytes staged in LDS per refill (16 bytes per lane and load)
+#endif
 
 struct ItxiLit {
     const uint8_t *lit;                    // the block's literal string (16-byte aligned)

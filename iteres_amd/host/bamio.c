@@ -114,10 +114,12 @@ struct aln_reader {
 
 /* ---- BGZF ------------------------------------------------------------------------------------------------ */
 static aln_device_ops dev;                   /* .push_begin == NULL: the host decodes */
+static int dev_nwin = ITX_BAMWIN_WINDOWS;   /* windows the pushes rotate through */
 void aln_use_device(const aln_device_ops *ops)
 {
     if (ops) dev = *ops;
     else memset(&dev, 0, sizeof dev);
+    dev_nwin = dev.n_windows >= 2 && dev.n_windows <= ITX_BAMWIN_WINDOWS ? dev.n_windows : ITX_BAMWIN_WINDOWS;
 }
 #define DEV_CHK(call, what)                                                                                    \
     do {                                                                                                       \
@@ -594,8 +596,10 @@ static void dev_begin(aln_reader *r)
     if (!max_blocks) {
         const char *e = getenv("ITX_DEV_WINDOW_BLOCKS");              /* tests: windows of a few blocks */
         const long x = e ? atol(e) : 0;
-        max_blocks = x >= 1 ? (size_t)x : DEV_MAX_BLOCKS;
+        max_blocks = x >= 1 ? (size_t)x : dev.max_blocks ? dev.max_blocks : DEV_MAX_BLOCKS;
+        if (dev.max_blocks && max_blocks > dev.max_blocks) max_blocks = dev.max_blocks;
     }
+    const size_t max_bytes = dev.max_bytes ? dev.max_bytes : DEV_MAX_BYTES;
     const long k = r->dk_begin;
     struct dev_job *j = &r->dj[k % ITX_BAMWIN_LANES];
     double tq = now_s();
@@ -604,7 +608,7 @@ static void dev_begin(aln_reader *r)
     t_io += now_s() - tq;
     size_t off = 0, utot = 0;
     int damaged = 0, capped = 0;
-    const size_t nb = r->clen ? index_blocks(r, max_blocks, DEV_MAX_BYTES, &off, &utot, &damaged, &capped) : 0;
+    const size_t nb = r->clen ? index_blocks(r, max_blocks, max_bytes, &off, &utot, &damaged, &capped) : 0;
     r->dmore = capped;
     if (j->bl_cap < nb + 1) {
         j->bl_cap = nb + nb / 4 + 1;
@@ -660,7 +664,7 @@ static void dev_begin(aln_reader *r)
     r->dstream_total += utot;
     j->nb = nb_use;
     j->cbase = r->cbuf;
-    j->w = (int)(k % ITX_BAMWIN_WINDOWS);
+    j->w = (int)(k % dev_nwin);
     j->last = damaged || share_done || (got == 0 && nb == 0);
     if (damaged && r->rg_on) r->rg_suspect = 1;
     static const uint8_t none[16];
@@ -705,6 +709,20 @@ static void dev_end(aln_reader *r)
     if (damaged && r->rg_on) r->rg_suspect = 1;
 }
 
+/* pushes kept in flight: pass 1 of the device decoder is a lane per block and latency-bound (a chunk's 8 k blocks take the
+ * same ~9 ms as 1 k would), so several chunks' pass 1 run side by side on a chip that one of them fills to a tenth;
+ * ITX_PUSHES (1 .. ITX_BAMWIN_LANES) overrides */
+static long pushes_in_flight(void)
+{
+    static long v;
+    if (!v) {
+        const char *e = getenv("ITX_PUSHES");
+        const long x = e ? atol(e) : 0;
+        v = x >= 1 && x <= ITX_BAMWIN_LANES ? x : ITX_BAMWIN_LANES;
+    }
+    return v;
+}
+
 /* The producer (read-ahead thread): begin a push whenever a window and a lane are free and input is left, end the oldest
  * one otherwise. */
 static void *dev_producer(void *arg)
@@ -715,7 +733,7 @@ static void *dev_producer(void *arg)
         int act = 0;                                               /* 1 begin, 2 end */
         while (!r->pf_stop) {
             const long begun = r->dk_begin, ready = r->dk_ready, cur = r->dk_cur;
-            if (!r->dinput_done && begun - cur < ITX_BAMWIN_WINDOWS && begun - ready < ITX_BAMWIN_LANES) {
+            if (!r->dinput_done && begun - cur < dev_nwin && begun - ready < pushes_in_flight()) {
                 act = 1;
                 break;
             }
@@ -734,7 +752,7 @@ static void *dev_producer(void *arg)
         } else {
             dev_end(r);
             pthread_mutex_lock(&r->pf_mu);
-            if (r->dring_eof[r->dk_ready % ITX_BAMWIN_WINDOWS]) r->dinput_done = 1;
+            if (r->dring_eof[r->dk_ready % dev_nwin]) r->dinput_done = 1;
             r->dk_ready++;
             pthread_cond_broadcast(&r->pf_cv);
         }
@@ -760,7 +778,7 @@ static size_t dev_advance(aln_reader *r)
         while (r->dk_ready <= nxt) pthread_cond_wait(&r->pf_cv, &r->pf_mu);
         pthread_mutex_unlock(&r->pf_mu);
     }
-    const int w = (int)(nxt % ITX_BAMWIN_WINDOWS);
+    const int w = (int)(nxt % dev_nwin);
     if (r->dk_cur >= 0) {
         if (r->rg_on && r->rg_lo_block) {
             /* a share that starts at a guessed record start: a record "too long to carry" is what a false start looks

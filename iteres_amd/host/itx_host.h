@@ -93,6 +93,10 @@ typedef struct aln_device_ops {
     void *(*alloc)(size_t bytes);
     void (*release)(void *p);
     const char *(*last_error)(void);
+    /* what the driver reserved on the device (itx_inflater_reserve): windows to rotate through, blocks / inflated bytes per push;
+     * zeros: the defaults (ITX_BAMWIN_WINDOWS, 16384 blocks, 1 GiB) with buffers that grow on demand */
+    int n_windows;
+    size_t max_blocks, max_bytes;
 } aln_device_ops;
 void aln_use_device(const aln_device_ops *ops);
 #define ALN_DEVICE_CHUNK (128u << 20)       /* compressed bytes per chunk handed to the device decoder (ITX_BGZF_CHUNK overrides) */

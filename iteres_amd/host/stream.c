@@ -64,11 +64,15 @@ static void pool_release(void *p)
     itx_pinned_free(p);
 }
 
+/* what the helper thread reserved on the device for the decoder (itx_inflater_reserve) */
+static int g_dev_windows;
+static size_t g_dev_max_blocks, g_dev_max_bytes;
+
 static void use_device_reader(void)
 {
     const aln_device_ops ops = {g_inflater,       itx_bamwin_push_begin, itx_bamwin_push_end, itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
                                 itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    itx_bamwin_tids,  itx_bamwin_device_batch,
-                                pool_alloc,      pool_release,     itx_last_error};
+                                pool_alloc,      pool_release,     itx_last_error,   g_dev_windows,       g_dev_max_blocks, g_dev_max_bytes};
     aln_use_device(&ops);
 }
 
@@ -110,6 +114,7 @@ static int plan_shares(char **files, int n_files, int splittable, int rank, int 
 }
 
 static int warm_splittable;
+static size_t warm_input_bytes;               /* size of all alignment files together (0: unknown) */
 
 static void *warm_main(void *arg)
 {
@@ -127,6 +132,26 @@ static void *warm_main(void *arg)
         for (int i = 0; i < 2 && i < POOL_N; i++) {
             pool[i].p = itx_pinned_alloc(want[i]);
             pool[i].cap = pool[i].p ? want[i] : 0;
+        }
+        /* the device side of the decoder, all of it, now that nothing runs there yet: windows and per-push scratch sized for
+         * the most a push may carry (the block indexer cuts a chunk that inflates to more into two pushes) */
+        const char *be = getenv("ITX_DEV_WINDOW_BLOCKS");
+        size_t max_blocks = be && atol(be) >= 1 ? (size_t)atol(be) : 12288;
+        /* no more than this rank's share of the input can need: a small file gets small buffers (a block of a real BAM takes
+         * kilobytes; a file of smaller ones is simply cut into more pushes by the indexer) */
+        if (warm_input_bytes) {
+            const size_t mine = warm_input_bytes / (size_t)(multi_world() > 0 ? multi_world() : 1);
+            const size_t est = mine / 2048 + 64;
+            if (!be && est < max_blocks) max_blocks = est;
+            const size_t nchunks = mine / chunk + 3;
+            if (nchunks < ITX_BAMWIN_WINDOWS) g_dev_windows = (int)nchunks;          /* in: the most this input can use */
+        }
+        const size_t max_bytes = max_blocks * 65280u < ((size_t)1 << 30) ? max_blocks * 65280u : (size_t)1 << 30;
+        if (!getenv("ITX_NO_RESERVE") && itx_inflater_reserve(g_inflater, chunk + (1u << 17), max_blocks, max_bytes, &g_dev_windows) == ITX_OK) {
+            g_dev_max_blocks = max_blocks;
+            g_dev_max_bytes = max_bytes;
+        } else {
+            g_dev_windows = 0;
         }
     }
     const double c = now_s();
@@ -160,6 +185,17 @@ void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file, int sp
         char *c = multi_file ? strchr(warm_first, ',') : NULL;
         warm_single = c == NULL;
         if (c) *c = 0;
+        char *all = xstrdup(aln_arg), *save = NULL;
+        warm_input_bytes = 0;
+        for (char *tok = multi_file ? strtok_r(all, ",", &save) : all; tok; tok = multi_file ? strtok_r(NULL, ",", &save) : NULL) {
+            struct stat sb;
+            if (stat(tok, &sb) == 0 && S_ISREG(sb.st_mode)) warm_input_bytes += (size_t)sb.st_size;
+            else {
+                warm_input_bytes = 0;                                   /* a pipe: no idea */
+                break;
+            }
+        }
+        free(all);
     }
     if (!warm_on && pthread_create(&warm_thread, NULL, warm_main, NULL) == 0) warm_on = 1;
 }

@@ -28,7 +28,7 @@ def main():
     ref = os.path.join(ROOT, "oracle", "_ref", "iteres")
     ours = os.path.join(ROOT, "iteres_amd", "host", "iteres")
     mk = os.path.join(ROOT, "tools", "mkbam")
-    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", mk, os.path.join(ROOT, "tools", "mkbam.c"), "-lz"])
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", mk, os.path.join(ROOT, "tools", "mkbam.c"), "-lz", "-ldl"])
     scale = n_rows / 5_500_000
     chroms = synth.HG38_CHROMS if scale == 1 else [(n, max(int(s * scale), 1000)) for n, s in synth.HG38_CHROMS]
     tmp = tempfile.mkdtemp(prefix="itx_e2e_", dir=os.environ.get("ITX_TMP", None))

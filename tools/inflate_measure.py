@@ -21,7 +21,7 @@ def main():
     seq_len = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     mk = os.path.join(ROOT, "tools", "mkbam")
-    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", mk, os.path.join(ROOT, "tools", "mkbam.c"), "-lz"])
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", mk, os.path.join(ROOT, "tools", "mkbam.c"), "-lz", "-ldl"])
     tmp = tempfile.mkdtemp(prefix="itx_inf_")
     synth.write_sizes(os.path.join(tmp, "chrom.sizes"), synth.HG38_CHROMS)
     subprocess.check_call([mk, os.path.join(tmp, "chrom.sizes"), str(n_reads), os.path.join(tmp, "reads.bam"), str(seq_len), "7"])

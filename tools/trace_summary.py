@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Scratch: what the device did during a traced CLI run (tools/trace_cli.sh): per kernel name count / total / mean, copies
+by direction, and the busy time of the union of all kernel intervals against the span they cover.
+    python tools/trace_summary.py <dir with cli_kernel_trace.csv / cli_memory_copy_trace.csv>"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+
+
+def rows(pat):
+    out = []
+    for f in glob.glob(os.path.join(d, "**", pat), recursive=True):
+        out += list(csv.DictReader(open(f)))
+    return out
+
+
+k = rows("*kernel_trace.csv")
+m = rows("*memory_copy_trace.csv")
+agg = defaultdict(lambda: [0, 0])
+iv = []
+for r in k:
+    a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    n = r["Kernel_Name"].split("(")[0][:40]
+    agg[n][0] += 1
+    agg[n][1] += b - a
+    iv.append((a, b, n))
+for n, (c, t) in sorted(agg.items(), key=lambda x: -x[1][1]):
+    print(f"{n:42s} {c:6d} calls {t / 1e6:10.2f} ms total {t / c / 1e3:10.1f} us mean")
+if iv:
+    iv.sort()
+    t0, t1 = iv[0][0], max(b for _, b, _ in iv)
+    busy, cur_a, cur_b = 0, iv[0][0], iv[0][1]
+    for a, b, _ in iv[1:]:
+        if a > cur_b:
+            busy += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    busy += cur_b - cur_a
+    print(f"kernels span {(t1 - t0) / 1e6:.1f} ms, some kernel running {busy / 1e6:.1f} ms ({100 * busy / (t1 - t0):.0f} %)")
+    for name in ("k_tokens", "k_resolve"):
+        sel = [(a, b) for a, b, n in iv if n.startswith(name)]
+        if sel:
+            sel.sort()
+            gaps = [sel[i + 1][0] - sel[i][0] for i in range(len(sel) - 1)]
+            gaps.sort()
+            print(f"{name}: start-to-start median {gaps[len(gaps) // 2] / 1e6:.2f} ms, span {(sel[-1][1] - sel[0][0]) / 1e6:.1f} ms")
+cp = defaultdict(lambda: [0, 0, 0])
+for r in m:
+    a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    key = r.get("Direction", "?")
+    cp[key][0] += 1
+    cp[key][1] += b - a
+    cp[key][2] += int(r.get("Size", 0) or 0) if "Size" in r else 0
+for kx, (c, t, sz) in cp.items():
+    print(f"copy {kx:22s} {c:6d} copies {t / 1e6:10.2f} ms total {sz / 1e9:8.2f} GB")

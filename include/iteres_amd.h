@@ -303,6 +303,10 @@ int itx_bamwin_bytes(itx_inflater *h, size_t off, void *dst, size_t len);
 int itx_bamwin_tids(itx_inflater *h, uint8_t *seen, int n_targets);
 int itx_bamwin_device_batch(itx_inflater *h, size_t first, int with_mates, itx_batch *out);
 
+/* ITX_TIMING: what the device decoder measured about itself (pushes, mean duration of the two passes, device allocations),
+ * one line on stderr; also printed when the process exits normally. */
+void itx_timing_report(void);
+
 /* Page-locked host memory for the buffers that cross PCIe on every call (NULL when it cannot be had). */
 void *itx_pinned_alloc(size_t bytes);
 void itx_pinned_free(void *p);

@@ -479,11 +479,16 @@ static double wall_now()
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+static bool g_reported;
 static void report_at_exit()
 {
+    if (g_reported || !g_pushes) return;
+    g_reported = true;
     fprintf(stderr, "[itx timing] device decoder: %lu pushes, pass 1 %.1f ms and pass 2 %.1f ms per push (HIP events, pushes overlap), %lu device allocations %.3f s\n", g_pushes,
             g_pushes ? g_tok_ms / (double)g_pushes : 0.0, g_pushes ? g_res_ms / (double)g_pushes : 0.0, g_allocs, g_alloc_s);
 }
+
+extern "C" void itx_timing_report(void) { report_at_exit(); }
 
 template <typename T> static int grow(T **p, size_t *cap, size_t need, bool exact = false)
 {

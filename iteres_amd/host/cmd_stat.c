@@ -208,11 +208,13 @@ int main_stat(int argc, char **argv)
         fprintf(stderr, "[itx timing] finish %.3f s, stat + wig files %.3f s, bigWig files + report %.3f s\n", t_finished - t_streamed,
                 t_stats - t_finished, now_s() - t_stats);
     }
+    const double t_free0 = now_s();
     itx_engine_destroy(eng);
     itx_table_destroy(tab);
     rmsk_free(&rm);
     sizes_free(&chr_sizes);
     sizes_free(&rep_sizes);
+    if (timing) fprintf(stderr, "[itx timing] engine, table and name tables released %.3f s\n", now_s() - t_free0);
     fprintf(stderr, "* Done, time used %.0f seconds.\n", difftime(time(NULL), start_time));
     return 0;
 }

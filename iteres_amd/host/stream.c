@@ -136,7 +136,8 @@ static void *warm_main(void *arg)
         /* the device side of the decoder, all of it, now that nothing runs there yet: windows and per-push scratch sized for
          * the most a push may carry (the block indexer cuts a chunk that inflates to more into two pushes) */
         const char *be = getenv("ITX_DEV_WINDOW_BLOCKS");
-        size_t max_blocks = be && atol(be) >= 1 ? (size_t)atol(be) : 12288;
+        const char *me = getenv("ITX_RESERVE_BLOCKS");                   /* scratch experiments */
+        size_t max_blocks = be && atol(be) >= 1 ? (size_t)atol(be) : me && atol(me) >= 64 ? (size_t)atol(me) : 12288;
         /* no more than this rank's share of the input can need: a small file gets small buffers (a block of a real BAM takes
          * kilobytes; a file of smaller ones is simply cut into more pushes by the indexer) */
         if (warm_input_bytes) {

@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--threads", type=int, default=0, help="host threads of the command (0: min(16, cores))")
     ap.add_argument("--workdir", default=os.environ.get("ITX_BENCH_DIR", ""))
     ap.add_argument("--keep", action="store_true", help="keep the generated inputs (they are reused when present)")
+    ap.add_argument("--no-replay-check", action="store_true", help="profiling runs: skip the small oracle-checked launch, so that every k_stream launch of this process has the replay's size")
     return ap.parse_args()
 
 
@@ -427,7 +428,7 @@ def main():
     # ---------------------------------------------------------------- roofline of the overlap kernel, records resident in HBM (rank 0)
     if rank == 0 and a.replay_steps > 0:
         n_res = a.replay_reads or a.reads
-        roof, rchecks = resident_roofline(a, n_res, a.replay_steps, rank, with_check=(world == 1))
+        roof, rchecks = resident_roofline(a, n_res, a.replay_steps, rank, with_check=(world == 1 and not a.no_replay_check))
         out["roofline"] = roof
         out["checks"].update(rchecks)
     if rank == 0:

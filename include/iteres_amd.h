@@ -303,6 +303,29 @@ int itx_bamwin_bytes(itx_inflater *h, size_t off, void *dst, size_t len);
 int itx_bamwin_tids(itx_inflater *h, uint8_t *seen, int n_targets);
 int itx_bamwin_device_batch(itx_inflater *h, size_t first, int with_mates, itx_batch *out);
 
+/* ---- the XA / NM multi-mapping veto on the device --------------------------------------------------------------------
+ * Replaces mapped2diffSubfam (generic.c:303-341) and its gate (generic.c:972-982) for the records of a window the device
+ * decoder has parsed: the XA:Z / NM tags are read where the inflated record lies, the alternatives with NM' <= NM are looked
+ * up in the table ("any overlapping row of another subfamily name", names compared without case), and the records the
+ * reference would drop get ITX_F5_NOLOOKUP in the window's flag5 array — before the window is handed to the engine.
+ *   create       row_rep[n_rows]: repName id of the caller's row i; rep_word[n_rep]: equal for names that sameWord() calls
+ *                equal; chrom_name[n_chrom]: the chromosome names in chrom_size[] order (hashRmsk's keys); p: the run's
+ *                parameters (the record's interval is re-derived for qlen, generic.c:764-905)
+ *   set_tidmap   per BAM header, as itx_engine_set_tidmap
+ *   hits/stream  where itx_engine_classify_device must leave the chosen rows of the batch, and on which stream
+ *   itx_bamwin_xa_veto  judges records [first, first + n) of the inflater's last parsed window (n <= batch_capacity):
+ *                *n_hard > 0: some record needs the host's reading (a number strtol(.., 0, 0) reads differently from plain
+ *                decimal, an alternative without four fields — where the reference asserts): NOTHING was marked, the caller
+ *                takes the host route for these records; else *n_vetoed records were marked. */
+typedef struct itx_xaveto itx_xaveto;
+int itx_xaveto_create(const itx_table *t, const itx_params *p, const uint32_t *row_rep, const uint32_t *rep_word, const char *const *chrom_name, int n_chrom,
+                      size_t batch_capacity, itx_xaveto **out);
+void itx_xaveto_destroy(itx_xaveto *x);
+int itx_xaveto_set_tidmap(itx_xaveto *x, const int32_t *tid2chrom, int n_tid);
+int32_t *itx_xaveto_hits(itx_xaveto *x);
+void *itx_xaveto_stream(itx_xaveto *x);
+int itx_bamwin_xa_veto(itx_inflater *h, itx_xaveto *x, size_t first, size_t n, uint64_t *n_vetoed, uint64_t *n_hard);
+
 /* ITX_TIMING: what the device decoder measured about itself (pushes, mean duration of the two passes, device allocations),
  * one line on stderr; also printed when the process exits normally. */
 void itx_timing_report(void);

@@ -989,6 +989,18 @@ extern "C" int itx_bamwin_tids(itx_inflater *h, uint8_t *seen, int n_targets)
     return ITX_OK;
 }
 
+int itx_xaveto_run(itx_xaveto *x, const uint8_t *u, const uint32_t *rec_off, const uint8_t *xa_mark, const int32_t *tid, const int32_t *pos, const int32_t *end,
+                   uint8_t *f5, const int32_t *mpos, const int32_t *isize, size_t n, uint64_t *n_vetoed, uint64_t *n_hard);      // itx_xaveto.hip
+
+/* the XA veto over records [first, first + n) of the last parsed window (chosen rows already in the veto object's buffer) */
+extern "C" int itx_bamwin_xa_veto(itx_inflater *h, itx_xaveto *x, size_t first, size_t n, uint64_t *n_vetoed, uint64_t *n_hard)
+{
+    if (!h || !x || !n_vetoed || !n_hard || first + n > h->n_rec) return ITX_E_ARG;
+    const int w = h->parsed_w;
+    return itx_xaveto_run(x, h->win[w].buf, h->d_recoff + first, h->d_xa + first, h->d_tid + first, h->d_pos + first, h->d_end + first, h->d_f5 + first,
+                          h->d_mpos + first, h->d_isize + first, n, n_vetoed, n_hard);
+}
+
 extern "C" int itx_bamwin_device_batch(itx_inflater *h, size_t first, int with_mates, itx_batch *out)
 {
     if (!h || !out || first > h->n_rec || (first & 15u)) return ITX_E_ARG;

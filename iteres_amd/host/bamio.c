@@ -1565,6 +1565,18 @@ void aln_readahead(aln_reader *r)
 
 size_t aln_device_left(const aln_reader *r) { return r->dev ? r->dn_rec - r->drec_next : 0; }
 
+int aln_device_xa_veto(aln_reader *r, itx_xaveto *x, size_t n, uint64_t *n_vetoed, uint64_t *n_hard)
+{
+    if (!r->dev || !dev.xa_veto || n > r->drec_next) return -1;
+    DEV_CHK(dev.xa_veto(dev.ctx, x, r->drec_next - n, n, n_vetoed, n_hard), "xa_veto");
+    return 0;
+}
+
+void aln_device_rewind(aln_reader *r)
+{
+    if (r->dev && r->dparsed) r->drec_next = 0;
+}
+
 int aln_device_exhausted(aln_reader *r) { return r->dev && !dev_ensure_records(r); }
 
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b)

@@ -97,6 +97,7 @@ typedef struct aln_device_ops {
      * zeros: the defaults (ITX_BAMWIN_WINDOWS, 16384 blocks, 1 GiB) with buffers that grow on demand */
     int n_windows;
     size_t max_blocks, max_bytes;
+    int (*xa_veto)(itx_inflater *, itx_xaveto *, size_t, size_t, uint64_t *, uint64_t *);      /* itx_bamwin_xa_veto */
 } aln_device_ops;
 void aln_use_device(const aln_device_ops *ops);
 #define ALN_DEVICE_CHUNK (128u << 20)       /* compressed bytes per chunk handed to the device decoder (ITX_BGZF_CHUNK overrides) */
@@ -107,6 +108,10 @@ void aln_use_device(const aln_device_ops *ops);
  * aln_read_batch_device: the next <= cap records of that window as device arrays, valid until the next reader call. */
 int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen);
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b);
+/* the XA veto over the batch aln_read_batch_device has just handed out (its chosen rows are in the veto object's buffer);
+ * aln_device_rewind: hand the current window's records out again from its first one (the host route after all) */
+int aln_device_xa_veto(aln_reader *r, itx_xaveto *x, size_t n, uint64_t *n_vetoed, uint64_t *n_hard);
+void aln_device_rewind(aln_reader *r);
 size_t aln_device_left(const aln_reader *r);  /* device decoder: records of the current window not yet taken */
 int aln_device_exhausted(aln_reader *r);
 void aln_readahead(aln_reader *r);            /* BAM: start decoding ahead of the first aln_read_batch */     /* device decoder: 1 when no record is left */
@@ -162,6 +167,7 @@ void dup_set_free(dup_set *s);
 int dup_set_seen(dup_set *s, uint32_t chr_name_id, const host_iv *d, int uniq);      /* generic.c:907-919: 1 = drop */
 typedef struct xa_index xa_index;
 xa_index *xa_index_new(const rmsk_t *rm);
+uint32_t *xa_rep_words(const rmsk_t *rm);            /* [reps.n] equal for names that differ only in case (sameWord); caller frees */
 void xa_index_free(xa_index *x);
 /* generic.c:303-341: 1 = veto. chosen_rep: repName id of the chosen row; xa is chopped in place. */
 int xa_veto(const xa_index *x, uint32_t chosen_rep, int nm, char *xa, int qlen);

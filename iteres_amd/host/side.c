@@ -159,21 +159,28 @@ static int cmp_xa_row(const void *a, const void *b)
     return x->s < y->s ? -1 : x->s > y->s;
 }
 
+/* rep_word[i] == rep_word[j] <=> sameWord(repName i, repName j) (cuskent/common.c:1316-1333: equal without case) */
+uint32_t *xa_rep_words(const rmsk_t *rm)
+{
+    names_t words;
+    names_init(&words);
+    uint32_t *w = xcalloc((size_t)rm->reps.n + 1, sizeof(uint32_t));
+    for (uint32_t i = 0; i < rm->reps.n; i++) {
+        char *u = xstrdup(rm->reps.name[i]);
+        for (char *p = u; *p; p++) *p = (char)toupper((unsigned char)*p);
+        w[i] = names_intern(&words, u);
+        free(u);
+    }
+    names_free(&words);
+    return w;
+}
+
 xa_index *xa_index_new(const rmsk_t *rm)
 {
     xa_index *x = xcalloc(1, sizeof *x);
     x->rm = rm;
     const uint32_t nc = rm->chroms.n;
-    names_t words;
-    names_init(&words);
-    x->rep_word = xcalloc((size_t)rm->reps.n + 1, sizeof(uint32_t));
-    for (uint32_t i = 0; i < rm->reps.n; i++) {
-        char *u = xstrdup(rm->reps.name[i]);
-        for (char *p = u; *p; p++) *p = (char)toupper((unsigned char)*p);
-        x->rep_word[i] = names_intern(&words, u);
-        free(u);
-    }
-    names_free(&words);
+    x->rep_word = xa_rep_words(rm);
     x->off = xcalloc((size_t)nc + 2, sizeof(uint32_t));
     for (size_t i = 0; i < rm->n_rows; i++) x->off[rm->row_chrom_name[i] + 1]++;
     for (uint32_t c = 0; c < nc; c++) x->off[c + 1] += x->off[c];

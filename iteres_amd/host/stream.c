@@ -72,7 +72,7 @@ static void use_device_reader(void)
 {
     const aln_device_ops ops = {g_inflater,       itx_bamwin_push_begin, itx_bamwin_push_end, itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
                                 itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    itx_bamwin_tids,  itx_bamwin_device_batch,
-                                pool_alloc,      pool_release,     itx_last_error,   g_dev_windows,       g_dev_max_blocks, g_dev_max_bytes};
+                                pool_alloc,      pool_release,     itx_last_error,   g_dev_windows,       g_dev_max_blocks, g_dev_max_bytes, itx_bamwin_xa_veto};
     aln_use_device(&ops);
 }
 
@@ -344,6 +344,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     names_t chr_names;                                                 /* identities of the chromosome strings inside -R keys */
     names_init(&chr_names);
     xa_index *xi = NULL;
+    itx_xaveto *xv = NULL;                                             /* the veto on the device (windows that stay in HBM) */
+    const int dev_veto = !getenv("ITX_HOST_VETO");
+    unsigned long long veto_dev_batches = 0, veto_host_batches = 0;
     FILE *bed_f = NULL, *bed_uniq_f = NULL;
     /* mustOpen, cuskent/common.c:2543-2568 */
     if (o->bed_path && !(bed_f = fopen(o->bed_path, "w"))) die("mustOpen: Can't open %s to write: %s", o->bed_path, strerror(errno));
@@ -430,6 +433,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             }
         }
         chk(itx_engine_set_tidmap(eng, t2c, nt > 0 ? nt : 0), "itx_engine_set_tidmap");
+        if (xv) chk(itx_xaveto_set_tidmap(xv, t2c, nt > 0 ? nt : 0), "itx_xaveto_set_tidmap");
         if (nt == 0) {
             /* no references: nothing can map; still count the read ends */
             int32_t none = -1;
@@ -448,9 +452,20 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                 const uint8_t *seen = NULL;
                 tq = now_s();
                 if (aln_device_window(rd, &wfl, &seen)) {
-                    if (veto_on && (wfl & 2)) direct = 0;
+                    /* a window with XA tags while the veto is on: the veto runs on the device too (itx_xaveto_*), as long as
+                     * the window is one batch; else, or when a record needs the host's reading, the host route as before */
+                    const int xa_window = veto_on && (wfl & 2);
+                    if (xa_window && (!dev_veto || aln_device_left(rd) > BATCH_RECORDS)) direct = 0;
                     for (int t = 0; t < nt && direct; t++)
                         if (seen[t] && t2c[t] == -1) direct = 0;
+                    if (direct && xa_window && !xv) {
+                        uint32_t *row_rep = xmalloc(sizeof(uint32_t) * (rm->n_rows + 1)), *words = xa_rep_words(rm);
+                        for (size_t i = 0; i < rm->n_rows; i++) row_rep[i] = rm->rows[i].rep;
+                        chk(itx_xaveto_create(tab, &p, row_rep, words, (const char *const *)chr_sizes->names.name, (int)n_chrom, BATCH_RECORDS, &xv), "itx_xaveto_create");
+                        chk(itx_xaveto_set_tidmap(xv, t2c, nt > 0 ? nt : 0), "itx_xaveto_set_tidmap");
+                        free(row_rep);
+                        free(words);
+                    }
                     if (direct) {
                         int wfl2;
                         do {
@@ -458,6 +473,22 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                             const size_t n = aln_read_batch_device(rd, BATCH_RECORDS, &db);
                             t_read += now_s() - tq;
                             if (n == 0) break;
+                            if (xa_window) {
+                                /* classify, let the device read the tags of the classified records, mark the vetoed ones */
+                                const double tv = now_s();
+                                uint64_t vetoed = 0, hard = 0;
+                                chk(itx_engine_classify_device(eng, &db, n, itx_xaveto_hits(xv), itx_xaveto_stream(xv)), "itx_engine_classify_device");
+                                if (aln_device_xa_veto(rd, xv, n, &vetoed, &hard) != 0) die("device veto: %s", itx_last_error());
+                                t_host += now_s() - tv;
+                                if (hard) {                                       /* an alternative only strtol / the reference's assert can judge */
+                                    aln_device_rewind(rd);
+                                    direct = 0;
+                                    tq = now_s();
+                                    break;
+                                }
+                                if (hc) hc->diff_subfam += vetoed;
+                                veto_dev_batches++;
+                            }
                             for (unsigned long long m = (ends / progress_every + 1) * progress_every; m <= ends + n; m += progress_every)
                                 fprintf(stderr, "\r* Processed read ends: %llu", m);
                             ends += n;
@@ -469,7 +500,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                             t_submit += now_s() - tq;
                             tq = now_s();
                         } while (!aln_device_window(rd, &wfl2, &seen));                        /* until the next window's start (or the end) */
-                        continue;
+                        if (direct) continue;
                     }
                 }
                 t_read += now_s() - tq;
@@ -565,6 +596,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             }
             /* ---- the XA veto needs the chosen row first: classify the slot, look, mark, then count (generic.c:972-982) */
             if (veto_on && batch_xa) {
+                veto_host_batches++;
                 if (!xi) xi = xa_index_new(rm);
                 chk(itx_engine_classify_slot(eng, s, n, any_paired), "itx_engine_classify_slot");
                 chk(itx_engine_wait_slot(eng, s), "itx_engine_wait_slot");
@@ -647,6 +679,8 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         }
     }
     }
+    if (timing && veto_on)
+        fprintf(stderr, "[itx timing] XA veto: %llu batches judged on the device, %llu by the host\n", veto_dev_batches, veto_host_batches);
     names_free(&warned);
     names_free(&chr_names);
     free(arg);
@@ -654,6 +688,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     if (bed_uniq_f) fclose(bed_uniq_f);
     dup_set_free(dups);
     xa_index_free(xi);
+    itx_xaveto_destroy(xv);
     free(iv);
     free(live);
 

@@ -338,8 +338,10 @@ def main():
     fence()
     t1 = time.perf_counter()
     last = None
+    step_walls = []
     for k in range(a.steps):
         last = one_run(weak_list, "step", k)
+        step_walls.append(round(last[0], 3))
         if world > 1:
             dist.barrier()
     fence()
@@ -389,6 +391,8 @@ def main():
             "scan_only": {"what": "banner to banner (stat.c:144,153): device table build + BAM decode + classify + accumulate, last step",
                           "seconds": round(scan_s, 3) if scan_s else None,
                           "M_alignments_per_s": round(a.reads * world / scan_s / 1e6, 2) if scan_s else None},
+            "step_wall_s": {"each": step_walls, "median": sorted(step_walls)[len(step_walls) // 2], "min": min(step_walls),
+                            "note": "rank 0's wall of every timed step; `value` is the mean over all of them (boxes of the pool differ: on some a run loses a second or more in device allocations)"},
             "phases_last_step": phases,
             "checks": checks,
             "inputs": info,

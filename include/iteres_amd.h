@@ -256,6 +256,9 @@ int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_len, const i
                      uint8_t *status);
 /* Device time of the two passes of the last call (Huffman -> tokens; first group of tokens -> bytes), milliseconds. */
 int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve_ms);
+/* ... and of pass 2 over ALL groups of that call; kernels only when the call was given out == NULL (the inflated bytes then
+ * stay on the device: timing runs) */
+int itx_inflater_last_resolve_all_ms(const itx_inflater *h, float *ms);
 
 /* ---- BAM records located and parsed on the device ---------------------------------------------------------------
  * Replaces bam_read1 (cussamtools/bam.c:179-210) and the field reads of the scan loop (generic.c:745-905 off
@@ -276,7 +279,8 @@ int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, float *resolve
  *   device_batch  records [first, ..) of the last parse as DEVICE arrays for itx_engine_submit_device* (first % 16 == 0;
  *             valid until the next parse)
  * Records are located by guess-and-verify (csrc/itx_inflate.hip): exact whatever the bytes look like. A record of
- * more than 4 MiB that straddles two chunks is beyond this path (ITX_E_LIMIT). One thread may push while another
+ * more than 4 MiB that straddles two chunks makes carry move the fresh bytes back (ITX_E_LIMIT only when the window's buffer
+ * cannot hold both). One thread may push while another
  * parses / fetches the OTHER window. */
 /* Before a stream of pushes, while the device is idle: every buffer the pushes will need, sized for chunks of at most
  * comp_bytes compressed bytes / max_blocks blocks / max_bytes inflated bytes, so that nothing is allocated (and, worse,

@@ -317,7 +317,8 @@ struct itx_inflater {
     itx_bgzf_block *d_blk;
     size_t comp_cap, out_cap, status_cap, blk_cap, lit_cap, tok_cap, meta_cap;
     hipEvent_t ev[4];
-    float ms_tokens, ms_resolve;
+    float ms_tokens, ms_resolve, ms_resolve_all;
+    hipEvent_t ev_res_end[2];
     // windows of inflated bytes that stay on the device (itx_bamwin_*)
     struct {
         uint8_t *buf;
@@ -368,6 +369,7 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     h->device = device;
     for (int k = 0; k < 2; k++) INF_HIP(hipStreamCreateWithFlags(&h->st[k], hipStreamNonBlocking));
     for (int k = 0; k < 4; k++) INF_HIP(hipEventCreate(&h->ev[k]));
+    for (int k = 0; k < 2; k++) INF_HIP(hipEventCreate(&h->ev_res_end[k]));
     for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
         INF_HIP(hipStreamCreateWithFlags(&h->lane[k].st, hipStreamNonBlocking));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].copied, hipEventDisableTiming));
@@ -516,7 +518,7 @@ template <typename T> static int grow(T **p, size_t *cap, size_t need, bool exac
 extern "C" int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_len, const itx_bgzf_block *blk, size_t n_blk, void *out, size_t out_len,
                                 uint8_t *status)
 {
-    if (!h || !comp || !blk || !out || !status) return ITX_E_ARG;
+    if (!h || !comp || !blk || !status) return ITX_E_ARG;          // out == NULL: the bytes stay on the device (timing runs)
     if (n_blk == 0) return ITX_OK;
     if (comp_len > 0xfffffff0u || out_len > 0xfffffff0u || n_blk > 0x7fffffffu) return ITX_E_LIMIT;
     // what the kernel assumes about every block, checked here: inside the buffers, outputs disjoint and in order
@@ -559,13 +561,20 @@ extern "C" int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_l
         INF_HIP(hipGetLastError());
         if (b0 == 0) INF_HIP(hipEventRecord(h->ev[3], h->st[0]));
         const size_t u0 = blk[b0].uoff, u1 = (size_t)blk[b1 - 1].uoff + blk[b1 - 1].usize;
-        if (u1 > u0) INF_HIP(hipMemcpyAsync((uint8_t *)out + u0, h->d_out + u0, u1 - u0, hipMemcpyDeviceToHost, h->st[s]));
+        if (out && u1 > u0) INF_HIP(hipMemcpyAsync((uint8_t *)out + u0, h->d_out + u0, u1 - u0, hipMemcpyDeviceToHost, h->st[s]));
+        INF_HIP(hipEventRecord(h->ev_res_end[s], h->st[s]));
         INF_HIP(hipMemcpyAsync(status + b0, h->d_status + b0, b1 - b0, hipMemcpyDeviceToHost, h->st[s]));
     }
     INF_HIP(hipStreamSynchronize(h->st[0]));
     INF_HIP(hipStreamSynchronize(h->st[1]));
     (void)hipEventElapsedTime(&h->ms_tokens, h->ev[0], h->ev[1]);
     (void)hipEventElapsedTime(&h->ms_resolve, h->ev[2], h->ev[3]);
+    {
+        float a = 0, b = 0;                                          // all groups of pass 2 (with the copies out, when there are any)
+        (void)hipEventElapsedTime(&a, h->ev[2], h->ev_res_end[0]);
+        if (per < n_blk) (void)hipEventElapsedTime(&b, h->ev[2], h->ev_res_end[1]);
+        h->ms_resolve_all = a > b ? a : b;
+    }
     return ITX_OK;
 }
 
@@ -575,6 +584,14 @@ extern "C" int itx_inflater_last_ms(const itx_inflater *h, float *tokens_ms, flo
     if (!h) return ITX_E_ARG;
     if (tokens_ms) *tokens_ms = h->ms_tokens;
     if (resolve_ms) *resolve_ms = h->ms_resolve;
+    return ITX_OK;
+}
+
+/* pass 2 over all groups of the last itx_inflate_bgzf call (kernels only when that call was given out == NULL) */
+extern "C" int itx_inflater_last_resolve_all_ms(const itx_inflater *h, float *ms)
+{
+    if (!h || !ms) return ITX_E_ARG;
+    *ms = h->ms_resolve_all;
     return ITX_OK;
 }
 
@@ -803,12 +820,34 @@ extern "C" int itx_bamwin_carry(itx_inflater *h, int from, int to)
 {
     if (!h || BAD_W(from) || BAD_W(to) || from == to) return ITX_E_ARG;
     const uint32_t tail = h->win[from].len - h->win[from].consumed;
-    if (tail > WIN_HEAD) {
-        itx_set_error("a BAM record of more than %u bytes straddles two chunks: beyond the device decoder (ITX_HOST_INFLATE=1 reads such files)", WIN_HEAD);
-        return ITX_E_LIMIT;
-    }
     if (h->win[to].start != WIN_HEAD) return ITX_E_STATE;
     INF_HIP(hipSetDevice(h->device));
+    if (tail > WIN_HEAD) {
+        // A record of more than 4 MiB straddles the chunks (a very long read): the head room in front of the fresh bytes is too
+        // small, so the fresh bytes move back instead — as long as the window's buffer holds both (the reference reads such
+        // files, bam.c:179-210 just reallocs; so does the host decoder).
+        const size_t fresh = h->win[to].len - WIN_HEAD;
+        if ((size_t)tail + fresh + 64 > h->win[to].cap || (size_t)tail + fresh > 0xfffffff0u) {
+            itx_set_error("a BAM record of more than %u bytes straddles two chunks and does not fit the window (%zu bytes): beyond the device decoder "
+                          "(ITX_HOST_INFLATE=1 reads such files)",
+                          tail, h->win[to].cap);
+            return ITX_E_LIMIT;
+        }
+        // move [WIN_HEAD, WIN_HEAD + fresh) to [tail, tail + fresh): from the end, in pieces no longer than the shift (no piece overlaps its source)
+        const size_t shift = (size_t)tail - WIN_HEAD;
+        for (size_t done = 0; done < fresh;) {
+            const size_t n = fresh - done < shift ? fresh - done : shift;
+            const size_t src = WIN_HEAD + fresh - done - n;
+            INF_HIP(hipMemcpyAsync(h->win[to].buf + src + shift, h->win[to].buf + src, n, hipMemcpyDeviceToDevice, h->st[1]));
+            done += n;
+        }
+        INF_HIP(hipMemcpyAsync(h->win[to].buf, h->win[from].buf + h->win[from].consumed, tail, hipMemcpyDeviceToDevice, h->st[1]));
+        INF_HIP(hipStreamSynchronize(h->st[1]));
+        h->win[to].start = h->win[to].consumed = 0;
+        h->win[to].len = tail + (uint32_t)fresh;
+        h->win[from].consumed = h->win[from].len;
+        return ITX_OK;
+    }
     if (tail) {
         INF_HIP(hipMemcpyAsync(h->win[to].buf + WIN_HEAD - tail, h->win[from].buf + h->win[from].consumed, tail, hipMemcpyDeviceToDevice, h->st[1]));
         INF_HIP(hipStreamSynchronize(h->st[1]));

@@ -610,13 +610,32 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             ITX_DPP_STEP(uadd32, inc, 0, 0x143, 0xc);
             uint32_t at = w_keys + inc - c;
             w_keys += (uint32_t)__builtin_amdgcn_readlane((int32_t)inc, 63);     // wave-uniform
+#ifdef ITX_LANE_RUNS
+            // keys per partition of this workgroup's region: a lane's four consecutive records mostly chose the same row, so
+            // their start marks fall into one partition — one LDS add per RUN of equal partitions inside the lane instead of
+            // one per key (the adds of a wave go to a handful of addresses and serialise there)
+            uint32_t pa[RPL];
+#pragma unroll
+            for (int j = 0; j < RPL; j++) pa[j] = sA[j] >> E.log_w;
+            uint32_t run = 0;
+#pragma unroll
+            for (int j = 0; j < RPL; j++) {
+                const bool v = hit[j] >= 0;
+                run += v ? 1u : 0u;
+                const bool flush = v && (j == RPL - 1 || hit[j + 1 < RPL ? j + 1 : j] < 0 || pa[j + 1 < RPL ? j + 1 : j] != pa[j]);
+                if (flush) atomicAdd(&s_pc[pa[j]], run);
+                run = flush ? 0u : run;
+            }
+#endif
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 const uint32_t u = uq[j] ? 4u : 0u;
                 const uint32_t lo = (hB[j] && !two[j]) ? (((sB[j] - sA[j]) << 3) | u) : (1u | u);
                 if (hit[j] >= 0) {
                     if (ITX_ABLATE_NOT(7)) w_out[at] = make_uint2(lo, sA[j]);
+#ifndef ITX_LANE_RUNS
                     if (ITX_ABLATE_NOT(6)) atomicAdd(&s_pc[sA[j] >> E.log_w], 1u);   // keys per partition of this workgroup's region
+#endif
                 }
                 at += hit[j] >= 0 ? 1u : 0u;
                 if (two[j]) {

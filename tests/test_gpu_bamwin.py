@@ -192,3 +192,41 @@ def test_records_longer_than_a_piece_and_a_block(win, tmp_path):
     comp = open(path, "rb").read()
     for chunk in (1 << 30, 300_000):
         check(win.read_all(comp, chunk), rd)
+
+
+def test_record_longer_than_the_head_room_straddles_chunks(tmp_path):
+    """A 5 MB record (a 3.3 M-base read) in a file the command pushes 300 KB at a time: its bytes pile up as the unconsumed tail
+    of window after window until they exceed the 4 MiB of head room in front of a window's fresh bytes — the carry then moves
+    the fresh bytes back instead of giving up (the reference and the host decoder read such files: bam.c:179-210 reallocs).
+    Through the command: the device route, the host decoder and (when it travelled) the reference binary give the same files."""
+    import dataclasses
+    import filecmp
+    import os
+    import subprocess
+    from iteres_amd import build
+    lib, exe = build.build_all()
+    chroms = [("c1", 50_000_000)]
+    t = synth.make_table(110, chroms, 30_000, n_names=200, n_fams=20, n_clas=8)
+    synth.write_sizes(str(tmp_path / "chrom.sizes"), chroms)
+    synth.write_sizes(str(tmp_path / "rep.sizes"), t.rep_len.items())
+    synth.write_rmsk(str(tmp_path / "rmsk.txt"), t)
+    a = synth.make_reads(111, chroms, 1, read_len=(3_300_000, 3_300_001))
+    b = synth.make_reads(112, chroms, 3000, read_len=(30, 200))
+    order = np.lexsort((np.concatenate([a.pos, b.pos]), np.concatenate([a.tid, b.tid])))
+    cat = lambda x, y: np.concatenate([x, y])[order]
+    r = dataclasses.replace(a, tid=cat(a.tid, b.tid), pos=cat(a.pos, b.pos), flag=cat(a.flag, b.flag), mapq=cat(a.mapq, b.mapq), l_qseq=cat(a.l_qseq, b.l_qseq),
+                            mtid=cat(a.mtid, b.mtid), mpos=cat(a.mpos, b.mpos), isize=cat(a.isize, b.isize),
+                            cigars=[(a.cigars + b.cigars)[i] for i in order], qname=[(a.qname + [f"s{i}" for i in range(len(b))])[i] for i in order])
+    synth.write_bam(str(tmp_path / "huge.bam"), r, with_seq=True)
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "iteres")
+    runs = [("dev", exe, {"ITX_BGZF_CHUNK": "300000"}), ("host", exe, {"ITX_HOST_INFLATE": "1"})] + ([("ref", ref, {})] if os.path.exists(ref) else [])
+    for name, prog, env in runs:
+        out = tmp_path / name
+        out.mkdir()
+        pr = subprocess.run([prog, "stat", "-w", "-o", "out", str(tmp_path / "chrom.sizes"), str(tmp_path / "rep.sizes"), str(tmp_path / "rmsk.txt"), str(tmp_path / "huge.bam")],
+                            cwd=out, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert pr.returncode == 0, pr.stderr[-1500:]
+    for name, _, _ in runs[1:]:
+        for fn in sorted(os.listdir(tmp_path / "dev")):
+            if not fn.endswith(".bigWig"):
+                assert filecmp.cmp(tmp_path / "dev" / fn, tmp_path / name / fn, shallow=False), (name, fn)

@@ -92,6 +92,15 @@ def main():
             a, b = os.path.join(tmp, "reference", fn), os.path.join(tmp, "drop_in", fn)
             same[fn] = os.path.exists(b) and filecmp.cmp(a, b, shallow=False)
         out["files_identical"] = same
+        # the two bigWigs by DECODED content (chromosomes, sections, zoom records, summary: tests/refio.py); their bytes depend on the zlib at hand
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import refio
+        bw = {}
+        for fn in sorted(os.listdir(os.path.join(tmp, "reference"))):
+            if fn.endswith(".bigWig"):
+                a, b = os.path.join(tmp, "reference", fn), os.path.join(tmp, "drop_in", fn)
+                bw[fn] = os.path.exists(b) and refio.bigwig_digest(open(a, "rb").read()) == refio.bigwig_digest(open(b, "rb").read())
+        out["bigwig_content_identical"] = bw
     print(json.dumps(out), flush=True)
 
 

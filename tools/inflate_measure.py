@@ -42,6 +42,14 @@ def main():
         a, b = C.c_float(), C.c_float()
         L.itx_inflater_last_ms(h._h, C.byref(a), C.byref(b))
         print(f"call {it}: {dt * 1e3:.1f} ms -> {total / dt / 1e9:.2f} GB/s inflated (pass 1 {a.value:.2f} ms, pass 2 first group {b.value:.2f} ms), bad blocks {int((status != 0).sum())}", flush=True)
+    # kernels only (nothing copied out): what the two passes do per launch of this many blocks
+    L.itx_inflater_last_resolve_all_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    for it in range(2):
+        eng._chk(L.itx_inflate_bgzf(h._h, cp, len(comp), eng._p(blocks), len(blocks), None, total, eng._p(status)), "inflate")
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        L.itx_inflater_last_ms(h._h, C.byref(a), C.byref(b))
+        L.itx_inflater_last_resolve_all_ms(h._h, C.byref(c))
+    print(f"kernels only, {len(blocks)} blocks / {total / 1e6:.0f} MB per launch: pass 1 {a.value:.2f} ms = {total / a.value / 1e6:.1f} GB/s, pass 2 (all groups) {c.value:.2f} ms = {total / c.value / 1e6:.1f} GB/s of inflated bytes", flush=True)
     out = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(total,))
     # every block against zlib (threads: zlib releases the GIL)
     from concurrent.futures import ThreadPoolExecutor

@@ -657,12 +657,21 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         uint64_t meta[4] = {hc ? hc->diff_subfam : 0, hc ? hc->dup_unique : 0, boundary_missed, ends};
         itx_comm *comm = NULL;
         const double tc = now_s();
-        chk(itx_comm_create(rank, world, multi_device(), multi_comm_id(), multi_comm_mode(), &comm), "itx_comm_create");
+        int comm_mode = multi_comm_mode();
+        int crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
+        if (crc != ITX_OK && comm_mode == ITX_COMM_RCCL) {
+            /* no RCCL communicator (no usable network interface for its bootstrap, say): the environment is the same for every
+             * rank, so they all end up here and hand their partials over through files — slower, same sums */
+            warnf("[iteres] note: %s; the ranks exchange through files instead", itx_last_error());
+            comm_mode = ITX_COMM_FILE;
+            crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
+        }
+        chk(crc, "itx_comm_create");
         const double ty = now_s();
         chk(itx_comm_reduce_sum(comm, p64, n64, p32, n32, meta, 4, NULL), "itx_comm_reduce_sum");
         if (timing && rank == 0)
             fprintf(stderr, "[itx timing] exchange (%s): export %.3f s, communicator %.3f s, reduce of %.1f MB per rank (waits for the slowest rank) %.3f s\n",
-                    multi_comm_mode() == ITX_COMM_FILE ? "files" : "RCCL", tc - tx, ty - tc, (double)(n64 * 8 + n32 * 4) / 1e6, now_s() - ty);
+                    comm_mode == ITX_COMM_FILE ? "files" : "RCCL", tc - tx, ty - tc, (double)(n64 * 8 + n32 * 4) / 1e6, now_s() - ty);
         itx_comm_destroy(comm);
         if (rank > 0) {                                              /* handed over: rank 0 writes the files */
             fflush(NULL);

@@ -49,6 +49,47 @@ if iv:
             gaps = [sel[i + 1][0] - sel[i][0] for i in range(len(sel) - 1)]
             gaps.sort()
             print(f"{name}: start-to-start median {gaps[len(gaps) // 2] / 1e6:.2f} ms, span {(sel[-1][1] - sel[0][0]) / 1e6:.1f} ms")
+# how the two decoder passes share the device: time with a pass-1 kernel running, a pass-2 kernel running, both, neither
+def union(sel):
+    sel = sorted(sel)
+    out = []
+    for a, b in sel:
+        if out and a <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], b)
+        else:
+            out.append([a, b])
+    return out
+
+
+def length(u):
+    return sum(b - a for a, b in u)
+
+
+def inter(u, v):
+    i = j = 0
+    tot = 0
+    while i < len(u) and j < len(v):
+        a, b = max(u[i][0], v[j][0]), min(u[i][1], v[j][1])
+        if b > a:
+            tot += b - a
+        if u[i][1] < v[j][1]:
+            i += 1
+        else:
+            j += 1
+    return tot
+
+
+tk = union([(a, b) for a, b, n in iv if n.startswith("k_tokens")])
+rs = union([(a, b) for a, b, n in iv if n.startswith("k_resolve")])
+if tk and rs:
+    lo, hi = min(tk[0][0], rs[0][0]), max(tk[-1][1], rs[-1][1])
+    both = inter(tk, rs)
+    print(f"decoder window {(hi - lo) / 1e6:.1f} ms: pass 1 running {length(tk) / 1e6:.1f} ms, pass 2 running {length(rs) / 1e6:.1f} ms, both {both / 1e6:.1f} ms, "
+          f"neither {((hi - lo) - length(tk) - length(rs) + both) / 1e6:.1f} ms")
+    # concurrency of pass-1 kernels among themselves: sum of durations / union
+    d1 = sum(b - a for a, b, n in iv if n.startswith("k_tokens"))
+    d2 = sum(b - a for a, b, n in iv if n.startswith("k_resolve"))
+    print(f"mean pass-1 kernels in flight while any runs: {d1 / max(length(tk), 1):.2f}; pass-2: {d2 / max(length(rs), 1):.2f}")
 cp = defaultdict(lambda: [0, 0, 0])
 for r in m:
     a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

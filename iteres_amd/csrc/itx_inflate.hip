@@ -51,12 +51,13 @@ static __device__ inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
 __global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp, const itx_bgzf_block *__restrict__ blk, uint32_t n, uint8_t *__restrict__ lit,
                                                uint32_t *__restrict__ tok, uint32_t *__restrict__ meta)
 {
-    __shared__ uint16_t s_lsym[288 * 64], s_dsym[32 * 64], s_offs[16 * 64], s_loffs[16 * 64], s_doffs[16 * 64];
-    __shared__ uint8_t s_lens[352 * 64];
+    __shared__ uint32_t s_lhi[9 * 64];
+    __shared__ uint16_t s_offs[16 * 64], s_loffs[16 * 64], s_doffs[16 * 64];
+    __shared__ uint8_t s_lsym8[288 * 64], s_dsym[32 * 64], s_lens[176 * 64];
     const uint32_t ln = threadIdx.x, b = blockIdx.x * 64u + ln;
     if (b >= n) return;
     const uint32_t coff = blk[b].coff, csize = blk[b].csize, usize = blk[b].usize;
-    ItxiTab T{s_lsym, s_dsym, s_offs, s_loffs, s_doffs, s_lens};
+    ItxiTab T{s_lsym8, s_lhi, s_dsym, s_offs, s_loffs, s_doffs, s_lens};
     ItxiTokens K{lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, 0, 0};
     int rc = ITXI_E_INPUT;
     if (csize >= BGZF_HEADER + BGZF_TRAILER + 2u && usize <= ITXI_MAX_BLOCK)

@@ -61,12 +61,23 @@ enum {
 
 // ---------------------------------------------------------------------------------------------------- pass 1: tokens
 
-struct ItxiTab {                           // one decoder's tables (element i through ITXI_AT)
-    uint16_t *lsym, *dsym;                 // [288], [32]: symbols in canonical order (by code length, then symbol)
-    uint16_t *offs;                        // [16]: scratch of the counting sort
+// One decoder's tables (element i through ITXI_AT), 628 bytes: on the device they live in LDS, a lane's worth per block, and
+// how many blocks pass 1 can hold at once is how much of it fits — 40 KB per wave of 64 blocks, four waves per CU (with
+// 16-bit symbols and a byte per code length it was 68 KB and two).
+struct ItxiTab {
+    uint8_t *lsym8;                        // [288]: literal/length symbols in canonical order (by code length, then symbol), low 8 bits
+    uint32_t *lhi;                         // [9]:   bit i of the bitmap: the symbol at canonical place i is >= 256
+    uint8_t *dsym;                         // [32]:  distance symbols in canonical order
+    uint16_t *offs;                        // [16]:  scratch of the counting sort
     uint16_t *loffs, *doffs;               // [16] each: itxi_decode's per-length offsets of the two codes in use
-    uint8_t *lens;                         // [352]: code lengths being set up: literal/length at 0, distance at 288, code-length code at 320
+    uint8_t *lens;                         // [176]: code lengths being set up, two to a byte: literal/length at 0, distance at 288, code-length code at 320
 };
+#define ITXI_LEN_GET(T, i) ((uint32_t)(ITXI_AT((T).lens, (i) >> 1) >> (((i) & 1u) * 4u)) & 15u)
+#define ITXI_LEN_SET(T, i, v)                                                                                     \
+    do {                                                                                                          \
+        const uint32_t i__ = (i), sh__ = (i__ & 1u) * 4u;                                                         \
+        ITXI_AT((T).lens, i__ >> 1) = (uint8_t)((ITXI_AT((T).lens, i__ >> 1) & ~(15u << sh__)) | (((v) & 15u) << sh__)); \
+    } while (0)
 
 struct ItxiCodes {
     // bound l (l = 1..15): every code of length <= l, written MSB first and left-aligned to 15 bits, is below it (the bounds
@@ -199,14 +210,14 @@ ITXI_FN uint32_t itxi_decode(const ItxiCodes &h, const uint16_t *offs, uint32_t 
 
 // Counting sort of `n` code lengths (T.lens[base ..]) into canonical order (puff.c construct()). Returns 0 for a complete
 // code, > 0 for an incomplete one (bits left over), < 0 for an over-subscribed one.
-ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint16_t *sym, uint16_t *offs_out, uint32_t base, uint32_t n, uint32_t &n_zero_or_one)
+ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, bool dist, uint16_t *offs_out, uint32_t base, uint32_t n, uint32_t &n_zero_or_one)
 {
     (void)ln;
     uint32_t cnt[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cnt[i] = 0;
     for (uint32_t s = 0; s < n; s++) {
-        const uint32_t l = ITXI_AT(T.lens, base + s);
+        const uint32_t l = ITXI_LEN_GET(T, base + s);
 #pragma unroll
         for (int i = 0; i < 16; i++) cnt[i] += (l == (uint32_t)i) ? 1u : 0u;
     }
@@ -224,11 +235,18 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, uint
         ITXI_AT(T.offs, len) = (uint16_t)o;
         o += cnt[len];
     }
+    if (!dist)
+        for (uint32_t k = 0; k < 9; k++) ITXI_AT(T.lhi, k) = 0;
     for (uint32_t s = 0; s < n; s++) {
-        const uint32_t l = ITXI_AT(T.lens, base + s);
+        const uint32_t l = ITXI_LEN_GET(T, base + s);
         if (l != 0) {
             const uint32_t at = ITXI_AT(T.offs, l);
-            ITXI_AT(sym, at) = (uint16_t)s;
+            if (dist) {
+                ITXI_AT(T.dsym, at) = (uint8_t)s;
+            } else {
+                ITXI_AT(T.lsym8, at) = (uint8_t)s;
+                if (s >= 256u) ITXI_AT(T.lhi, at >> 5) |= 1u << (at & 31u);
+            }
             ITXI_AT(T.offs, l) = (uint16_t)(at + 1u);
         }
     }
@@ -316,23 +334,23 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
             if (type == 1) {
                 nl = 288;
                 nd = 30;
-                for (uint32_t s = 0; s < 288; s++) ITXI_AT(T.lens, s) = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8);
-                for (uint32_t s = 0; s < 30; s++) ITXI_AT(T.lens, 288 + s) = 5;
+                for (uint32_t s = 0; s < 288; s++) ITXI_LEN_SET(T, s, (s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u));
+                for (uint32_t s = 0; s < 30; s++) ITXI_LEN_SET(T, 288 + s, 5u);
             } else {
                 itxi_refill(in);
                 nl = itxi_bits(in, 5) + 257u;
                 nd = itxi_bits(in, 5) + 1u;
                 const uint32_t nc = itxi_bits(in, 4) + 4u;
                 if (nl > 286u || nd > 30u) return ITXI_E_CODES;
-                for (uint32_t s = 0; s < 19; s++) ITXI_AT(T.lens, 320 + s) = 0;
+                for (uint32_t s = 0; s < 19; s++) ITXI_LEN_SET(T, 320 + s, 0u);
                 for (uint32_t i = 0; i < nc; i++) {
                     itxi_refill(in);
-                    ITXI_AT(T.lens, 320 + clorder[i]) = (uint8_t)itxi_bits(in, 3);
+                    ITXI_LEN_SET(T, 320 + clorder[i], itxi_bits(in, 3));
                 }
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
                 ItxiCodes cc;
                 uint32_t n01;
-                if (itxi_construct(T, ln, cc, T.lsym, T.loffs, 320, 19, n01) != 0) return ITXI_E_CODES;         // must be complete
+                if (itxi_construct(T, ln, cc, false, T.loffs, 320, 19, n01) != 0) return ITXI_E_CODES;           // must be complete
                 // code lengths of the literal/length and distance codes, run-length coded as ONE sequence (a run may
                 // cross from one code into the other); entry idx of it lives at place(idx)
 #define ITXI_PLACE(i) ((i) < nl ? (i) : 288u + ((i) - nl))
@@ -343,15 +361,15 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                     const uint32_t at = itxi_decode(cc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);
                     if (cl == 0) return ITXI_E_SYMBOL;
                     itxi_bits(in, cl);
-                    const uint32_t sym = ITXI_AT(T.lsym, at);
+                    const uint32_t sym = ITXI_AT(T.lsym8, at);
                     if (sym < 16) {
-                        ITXI_AT(T.lens, ITXI_PLACE(idx)) = (uint8_t)sym;
+                        ITXI_LEN_SET(T, ITXI_PLACE(idx), sym);
                         idx++;
                     } else {
                         uint32_t rep, val = 0;
                         if (sym == 16) {
                             if (idx == 0) return ITXI_E_CODES;
-                            val = ITXI_AT(T.lens, ITXI_PLACE(idx - 1));
+                            val = ITXI_LEN_GET(T, ITXI_PLACE(idx - 1));
                             rep = 3u + itxi_bits(in, 2);
                         } else if (sym == 17) {
                             rep = 3u + itxi_bits(in, 3);
@@ -359,18 +377,18 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                             rep = 11u + itxi_bits(in, 7);
                         }
                         if (idx + rep > nl + nd) return ITXI_E_CODES;
-                        for (uint32_t k = 0; k < rep; k++) ITXI_AT(T.lens, ITXI_PLACE(idx + k)) = (uint8_t)val;
+                        for (uint32_t k = 0; k < rep; k++) ITXI_LEN_SET(T, ITXI_PLACE(idx + k), val);
                         idx += rep;
                     }
                     if (itxi_overrun(in)) return ITXI_E_INPUT;
                 }
 #undef ITXI_PLACE
-                if (ITXI_AT(T.lens, 256) == 0) return ITXI_E_CODES;                              // no end-of-block code
+                if (ITXI_LEN_GET(T, 256u) == 0) return ITXI_E_CODES;                             // no end-of-block code
             }
             uint32_t n01;
-            int32_t left = itxi_construct(T, ln, lc, T.lsym, T.loffs, 0, nl, n01);
+            int32_t left = itxi_construct(T, ln, lc, false, T.loffs, 0, nl, n01);
             if (type == 2 && left != 0 && (left < 0 || nl != n01)) return ITXI_E_CODES;          // the fixed code is incomplete by definition
-            left = itxi_construct(T, ln, dc, T.dsym, T.doffs, 288, nd, n01);
+            left = itxi_construct(T, ln, dc, true, T.doffs, 288, nd, n01);
             if (type == 2 && left != 0 && (left < 0 || nd != n01)) return ITXI_E_CODES;
 
             for (;;) {                                             // one symbol per turn; each produces output or ends the block
@@ -379,7 +397,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 uint32_t at = itxi_decode(lc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);
                 if (cl == 0) return ITXI_E_SYMBOL;
                 itxi_bits(in, cl);
-                const uint32_t sym = ITXI_AT(T.lsym, at);
+                const uint32_t sym = (uint32_t)ITXI_AT(T.lsym8, at) | (((ITXI_AT(T.lhi, at >> 5) >> (at & 31u)) & 1u) << 8);
                 if (sym < 256u) {
                     if (itxi_past(in)) return ITXI_E_INPUT;       // literals out of the bytes behind the block: stop before the padding ends
                     if (produced >= usize) return ITXI_E_OUTPUT;

@@ -31,14 +31,15 @@ static inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
 extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, uint32_t data_end, uint8_t *out, uint32_t g0, uint32_t usize,
                                 uint32_t *n_lit, uint32_t *n_tok)
 {
-    static thread_local uint16_t lsym[288], dsym[32], offs[16], loffs[16], doffs[16];
-    static thread_local uint8_t lens[352];
+    static thread_local uint16_t offs[16], loffs[16], doffs[16];
+    static thread_local uint8_t lsym8[288], dsym[32], lens[176];
+    static thread_local uint32_t lhi[9];
     static thread_local uint32_t ring32[ITXI_RING / 4], stage32[ITXI_LSTAGE / 4];
     static thread_local std::vector<uint32_t> lit32(ITXI_MAX_BLOCK / 4 + 4);
     uint8_t *lit = reinterpret_cast<uint8_t *>(lit32.data());
     static thread_local std::vector<uint32_t> tok(2 * ITXI_MAX_TOK);
     if (usize > ITXI_MAX_BLOCK) return ITXI_E_OUTPUT;
-    ItxiTab T{lsym, dsym, offs, loffs, doffs, lens};
+    ItxiTab T{lsym8, lhi, dsym, offs, loffs, doffs, lens};
     ItxiTokens K{lit, tok.data(), 0, 0};
     int rc = itxi_tokens(T, 0, comp_words, data_pos, data_end, usize, K);
     if (n_lit) *n_lit = K.n_lit;

@@ -160,9 +160,16 @@ struct ItxDevBatch {
 enum { ITX_DO_CLASSIFY = 0, ITX_DO_ATOMIC_STAT = 1, ITX_DO_ATOMIC_LOCUS = 2, ITX_DO_EMIT = 3,
        ITX_DO_FIND_FIRST = 4 /* plain intervals (pos, tmpend): first overlapping row in binKeeperFind's order, nothing else */ };
 #define ITX_STREAM_LB 5             // workgroups of the streaming kernel per CU its register budget is set for (96 VGPRs)
-// Workgroups of a streaming launch: one full wave of the chip (CUs x ITX_STREAM_LB), each walking one contiguous
-// span of records; ITX_STREAM_BLOCKS overrides (experiments), 2048 bounds the per-region bookkeeping.
-unsigned itx_stream_blocks(int device);
+// Workgroups of a streaming launch over n records: whole ROUNDS of what the chip holds at once (CUs x ITX_STREAM_LB), each
+// workgroup walking one contiguous region of about ITX_STREAM_REGION records. One round of long regions ends with the chip
+// half empty while the slowest regions finish (measured at 500 M records: 1 round 2.96 ms, 12 rounds 2.71 ms, and the
+// scatter that follows 1.36 -> 1.03 ms); regions much shorter than this cost the partition path more in bookkeeping than
+// the balance gains (50 M records: best at one round = 39 k records each). ITX_STREAM_BLOCKS / _REGION / _ROUNDS override.
+#define ITX_STREAM_REGION 32768u
+#define ITX_STREAM_ROUNDS 16u
+unsigned itx_stream_blocks(int device, size_t n);
+// span of records per workgroup (a multiple of the stream tile) and the workgroups that cover n records with it
+void itx_stream_plan(unsigned blocks, size_t n, size_t *span, unsigned *n_blocks);
 #define ITX_STREAM_TILE 1024u      // records per workgroup iteration (4 waves x 64 lanes x 4 records)
 #define ITX_PART_SUB 8u            // sub-cursors per partition (partition path)
 // What the emitting launch needs to know about the partition path's bookkeeping.

@@ -41,7 +41,6 @@ struct itx_engine {
     double stage_ms[5];
     uint64_t records, submits, keys;
     ItxPartWork *pw;      // scratch of the partition path
-    unsigned max_blocks;
 };
 
 static int use_device(const itx_engine *e)
@@ -99,7 +98,6 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     e->records = e->submits = e->keys = 0;
     memset(e->stage_ms, 0, sizeof e->stage_ms);
     e->pw = nullptr;
-    e->max_blocks = itx_stream_blocks(t->device);
     hipError_t he = hipMalloc((void **)&e->u64, (partial_u64(e) + 2) * sizeof(uint64_t));
     if (he == hipSuccess) he = hipMemset(e->u64, 0, (partial_u64(e) + 2) * sizeof(uint64_t));
     if (he == hipSuccess) he = hipMalloc((void **)&e->u32, (e->L.n_u32 + 4) * sizeof(uint32_t));
@@ -282,9 +280,9 @@ static int run_batch(itx_engine *e, const ItxDevBatch &B, size_t n, int32_t *d_h
     if (accumulate && e->p.accum == ITX_ACCUM_PARTITION) {
         rc = itx_part_run(e->pw, e->t->dev, P, B, n, d_hit_row, e->u64, e->u32, e->L, st);
     } else {
-        size_t span = (n + e->max_blocks - 1) / e->max_blocks;
-        span = (span + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
-        const unsigned nb = (unsigned)((n + span - 1) / span);
+        size_t span;
+        unsigned nb;
+        itx_stream_plan(itx_stream_blocks(e->t->device, n), n, &span, &nb);
         const int what = kind == RUN_FIND_FIRST ? ITX_DO_FIND_FIRST
                          : !accumulate         ? ITX_DO_CLASSIFY
                                                : (e->p.mode == ITX_MODE_STAT ? ITX_DO_ATOMIC_STAT : ITX_DO_ATOMIC_LOCUS);

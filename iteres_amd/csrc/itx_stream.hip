@@ -683,16 +683,42 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     }
 }
 
-unsigned itx_stream_blocks(int device)
+unsigned itx_stream_blocks(int device, size_t n)
 {
     if (const char *s = getenv("ITX_STREAM_BLOCKS")) {
         const long v = atol(s);
-        if (v >= 1 && v <= 2048) return (unsigned)v;
+        if (v >= 1 && v <= 32768) return (unsigned)v;
     }
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-    const unsigned b = (unsigned)cus * ITX_LB;
-    return b > 2048u ? 2048u : b;
+    static int cus_of[64];                                  // 0: not asked yet
+    int cus = device >= 0 && device < 64 ? cus_of[device] : 0;
+    if (cus <= 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        if (device >= 0 && device < 64) cus_of[device] = cus;
+    }
+    unsigned one = (unsigned)cus * ITX_LB;                  // what the chip holds at once
+    if (one > 2048u) one = 2048u;
+    size_t target = ITX_STREAM_REGION;
+    if (const char *s = getenv("ITX_STREAM_REGION")) {
+        const long v = atol(s);
+        if (v >= 1024) target = (size_t)v;
+    }
+    size_t max_rounds = ITX_STREAM_ROUNDS;
+    if (const char *s = getenv("ITX_STREAM_ROUNDS")) {
+        const long v = atol(s);
+        if (v >= 1 && v <= 64) max_rounds = (size_t)v;
+    }
+    size_t rounds = (n + (size_t)one * target / 2) / ((size_t)one * target);
+    rounds = rounds < 1 ? 1 : rounds > max_rounds ? max_rounds : rounds;
+    return one * (unsigned)rounds;
+}
+
+void itx_stream_plan(unsigned blocks, size_t n, size_t *span, unsigned *n_blocks)
+{
+    size_t sp = (n + blocks - 1) / blocks;
+    sp = (sp + ITX_STREAM_TILE - 1) / ITX_STREAM_TILE * ITX_STREAM_TILE;
+    if (sp == 0) sp = ITX_STREAM_TILE;
+    *span = sp;
+    *n_blocks = (unsigned)((n + sp - 1) / sp);
 }
 
 int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, const ItxDevBatch &B, size_t n, size_t span,

@@ -110,7 +110,7 @@ extern "C" int itx_engine_create(const itx_table *t, const itx_params *p, size_t
     if (e->p.accum == ITX_ACCUM_PARTITION) {
         int rc = itx_part_create(t, batch_capacity, &e->pw);
         if (rc == ITX_E_LIMIT && accum_default) {
-            // a slot space beyond the partition path's window table (> 4096 x 8192 consensus slots): the device atomics
+            // a slot space beyond the partition path's widest partitions (> 4096 x 65536 consensus slots): the device atomics
             // path gives the same sums, slower; only an explicit ITX_ACCUM_PARTITION request fails
             e->p.accum = ITX_ACCUM_ATOMIC;
             e->pw = nullptr;

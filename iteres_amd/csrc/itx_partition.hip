@@ -42,6 +42,7 @@
 struct ItxPartWork {
     size_t cap;            // records per batch
     uint32_t n_part;       // partitions
+    uint32_t log_w;        // log2(slots per partition): ITX_LOGW .. 16 (the smallest that keeps n_part <= ITX_MAXP)
     uint32_t max_blocks;   // workgroups of the emit launch (regions are per workgroup)
     int device;
     uint32_t max_items;
@@ -61,15 +62,25 @@ static inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 
 int itx_part_create(const itx_table *t, size_t cap, ItxPartWork **out)
 {
-    const uint32_t n_part = (t->n_slots + ITX_W - 1) >> ITX_LOGW;
+    // A partition is one or more LDS windows of k_hist (2^ITX_LOGW slots each): as many as keep the partitions within what
+    // the per-region LDS tables of k_stream / k_scatter hold. Up to 2^16 slots per partition the 4-byte keys of k_scatter
+    // still carry slot-in-partition (16 bits) + length (13) + type/uniq (3).
+    uint32_t log_w = ITX_LOGW;
+    if (const char *s = getenv("ITX_PART_LOGW")) {                         // tests: wide partitions on a small slot space
+        const long v = atol(s);
+        if (v >= (long)ITX_LOGW && v <= 16) log_w = (uint32_t)v;
+    }
+    while (log_w < 16 && (((uint64_t)t->n_slots + (1ull << log_w) - 1) >> log_w) > ITX_MAXP) log_w++;
+    const uint32_t n_part = (uint32_t)(((uint64_t)t->n_slots + (1ull << log_w) - 1) >> log_w);
     if (n_part > ITX_MAXP) {
-        itx_set_error("partition path: %u consensus slots need %u partitions (> %u); use ITX_ACCUM_ATOMIC", t->n_slots, n_part,
+        itx_set_error("partition path: %u consensus slots need %u partitions of 65536 (> %u); use ITX_ACCUM_ATOMIC", t->n_slots, n_part,
                       ITX_MAXP);
         return ITX_E_LIMIT;
     }
     ItxPartWork *w = new ItxPartWork();
     w->cap = cap;
     w->n_part = n_part ? n_part : 1;
+    w->log_w = log_w;
     w->device = t->device;
     w->max_blocks = itx_stream_blocks(t->device, cap);
     w->max_items = w->n_part + (uint32_t)((2 * cap) / ITX_CHUNK) + 2;
@@ -161,8 +172,8 @@ __device__ __forceinline__ void block_excl_scan2(uint32_t a, uint32_t b, uint32_
 
 __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0, const uint32_t *__restrict__ blk_cnt, size_t span,
                                                 const uint32_t *__restrict__ subcur, const uint32_t *__restrict__ offm,
-                                                uint32_t *__restrict__ keys1, uint32_t n_part, uint4 *__restrict__ items,
-                                                uint32_t *__restrict__ n_items)
+                                                uint32_t *__restrict__ keys1, uint32_t n_part, uint32_t log_w,
+                                                uint4 *__restrict__ items, uint32_t *__restrict__ n_items)
 {
     extern __shared__ uint32_t s_cur[];                       // [n_part] next free place of this region in each partition
     const uint32_t sub = blockIdx.x & (ITX_SUB - 1);
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0,
     }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wmask = (1u << log_w) - 1u;
     // 8 rounds of 256 keys per iteration: the loads of all eight are in flight before the first is used
     // (one round after the other leaves the kernel waiting on one global load per 256 keys per workgroup)
     constexpr int U = 8;
@@ -243,23 +255,27 @@ __global__ __launch_bounds__(PB) void k_scatter(const uint2 *__restrict__ keys0,
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const bool has = key[u].y != 0xffffffffu;
-                const uint32_t p = has ? key[u].y >> ITX_LOGW : 0xffffffffu;
+                const uint32_t p = has ? key[u].y >> log_w : 0xffffffffu;
                 uint32_t len, leader;
                 const bool st = wave_run(p, has, lane, &len, &leader);
                 uint32_t base = 0;
                 if (st) base = atomicAdd(&s_cur[p], len);             // one returning LDS add per run
                 base = (uint32_t)__shfl((int32_t)base, (int)leader, 64);
-                if (has) keys1[base + (lane - leader)] = ((key[u].y & (ITX_W - 1)) << 16) | (key[u].x & 0xffffu);
+                if (has) keys1[base + (lane - leader)] = ((key[u].y & wmask) << 16) | (key[u].x & 0xffffu);
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ H
+// WIDE: a partition spans several LDS windows (log_w > ITX_LOGW, slot spaces beyond ITX_MAXP x 2^ITX_LOGW): the item's keys
+// are read once per window and each pass keeps the marks that fall into its window.
+template <bool WIDE>
 __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1, const uint4 *__restrict__ items,
                                              const uint32_t *__restrict__ n_items, uint32_t *__restrict__ u32, uint64_t *__restrict__ u64,
                                              ItxAccumLayout L, uint32_t n_slots, const uint32_t *__restrict__ unit_slot,
-                                             const uint32_t *__restrict__ part_unit, uint32_t *__restrict__ subcur, uint32_t n_sub)
+                                             const uint32_t *__restrict__ part_unit, uint32_t *__restrict__ subcur, uint32_t n_sub,
+                                             uint32_t log_w)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_a[ITX_W], s_b[ITX_W];   // packed all:16 | uniq:16
     // the sub-totals have done their job (k_scatter is through): zero them for the next batch's reservations
@@ -267,7 +283,11 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
     const uint32_t nI = *n_items;
     for (uint32_t it = blockIdx.x; it < nI; it += gridDim.x) {
         const uint4 item = items[it];
-        const uint32_t slot0 = item.x << ITX_LOGW;
+        const uint32_t n_win = WIDE ? 1u << (log_w - ITX_LOGW) : 1u;
+        for (uint32_t h = 0; h < n_win; h++) {
+        const uint32_t off = h << ITX_LOGW;                          // the window's first slot inside the partition
+        const uint32_t slot0 = WIDE ? (item.x << log_w) + off : item.x << ITX_LOGW;
+        if (WIDE && slot0 >= n_slots) break;                         // the last partition may end early
         for (uint32_t k = threadIdx.x; k < ITX_W; k += HB) {
             s_a[k] = 0;
             s_b[k] = 0;
@@ -285,8 +305,14 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
                 if (key[u] != 0xffffffffu) {
                     const uint32_t sl = key[u] >> 16, type = key[u] & 3u, len = (key[u] >> 3) & (ITX_W - 1);
                     const uint32_t v = 1u | ((key[u] & 4u) << 14);
-                    if (type != 2u) atomicAdd(&s_a[sl], v);                      // start mark
-                    if (type != 1u) atomicAdd(&s_b[sl + len], v);                // end mark (len == 0 for type 2)
+                    if (WIDE) {
+                        const uint32_t a = sl - off, b = sl + len - off;         // below the window: wraps to a huge number
+                        if (type != 2u && a < ITX_W) atomicAdd(&s_a[a], v);
+                        if (type != 1u && b < ITX_W) atomicAdd(&s_b[b], v);
+                    } else {
+                        if (type != 2u) atomicAdd(&s_a[sl], v);                  // start mark
+                        if (type != 1u) atomicAdd(&s_b[sl + len], v);            // end mark (len == 0 for type 2)
+                    }
                 }
             }
         }
@@ -297,7 +323,7 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
         // slot when it adds no coverage); waves take the units that reach into this window in turn
         {
             const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-            for (uint32_t u = part_unit[item.x] + wave; u < (uint32_t)L.n_units; u += HB / 64) {
+            for (uint32_t u = part_unit[WIDE ? (item.x << (log_w - ITX_LOGW)) + h : item.x] + wave; u < (uint32_t)L.n_units; u += HB / 64) {
                 const uint32_t us = unit_slot[u], ue = unit_slot[u + 1];
                 if (us >= slot0 + lim) break;
                 const uint32_t lo = us > slot0 ? us - slot0 : 0u, hi = ue < slot0 + lim ? ue - slot0 : lim;
@@ -357,6 +383,7 @@ __global__ __launch_bounds__(HB) void k_hist(const uint32_t *__restrict__ keys1,
             }
         }
         __syncthreads();
+        }
     }
 }
 
@@ -377,12 +404,12 @@ int itx_part_run(ItxPartWork *w, const ItxDevTable &T, const ItxRunParams &P, co
     hipEvent_t ev[4];
     for (int k = 0; k < 4; k++) ITX_HIP(hipEventCreate(&ev[k]));
     ITX_HIP(hipEventRecord(ev[0], st));
-    ItxEmitPlan E = {w->subcur, w->offm, w->n_part, ITX_LOGW};
+    ItxEmitPlan E = {w->subcur, w->offm, w->n_part, w->log_w};
     int rc = itx_launch_stream(ITX_DO_EMIT, T, P, B, n, span, nb, d_hit_row, u64, u32, L, w->keys0, w->blk_cnt, E, st);
     if (rc) return rc;
     ITX_HIP(hipEventRecord(ev[1], st));
     hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(PB), (size_t)w->n_part * 4, st, w->keys0, w->blk_cnt, span, w->subcur, w->offm, w->keys1,
-                       w->n_part, w->items, w->n_items);
+                       w->n_part, w->log_w, w->items, w->n_items);
     ITX_HIP(hipGetLastError());
     ITX_HIP(hipEventRecord(ev[2], st));
     static const unsigned hist_blocks = [] {
@@ -390,8 +417,12 @@ int itx_part_run(ItxPartWork *w, const ItxDevTable &T, const ItxRunParams &P, co
         const long v = s ? atol(s) : 0;
         return v >= 64 && v <= 65536 ? (unsigned)v : 4096u;   // items are dealt round robin: enough workgroups that the hardware balances them (500 M records: 1024 -> 0.96 ms, 4096 -> 0.88)
     }();
-    hipLaunchKernelGGL(k_hist, dim3(hist_blocks), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, u64, L, T.n_slots, T.unit_slot, T.part_unit,
-                       w->subcur, w->n_part * ITX_SUB);
+    if (w->log_w > ITX_LOGW)
+        hipLaunchKernelGGL(k_hist<true>, dim3(hist_blocks), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, u64, L, T.n_slots, T.unit_slot,
+                           T.part_unit, w->subcur, w->n_part * ITX_SUB, w->log_w);
+    else
+        hipLaunchKernelGGL(k_hist<false>, dim3(hist_blocks), dim3(HB), 0, st, w->keys1, w->items, w->n_items, u32, u64, L, T.n_slots, T.unit_slot,
+                           T.part_unit, w->subcur, w->n_part * ITX_SUB, w->log_w);
     ITX_HIP(hipGetLastError());
     ITX_HIP(hipEventRecord(ev[3], st));
     for (int k = 0; k < 4; k++) w->ev.push_back(ev[k]);

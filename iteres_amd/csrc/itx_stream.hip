@@ -587,7 +587,8 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             }
         } else if (WHAT == ITX_DO_EMIT) {
             // One 8-byte key per classified record: low word = type | uniq << 2 | len << 3, high word = slot.
-            //   type 0: a start mark at slot and an end mark at slot + len (both inside one partition, len < 2^13)
+            //   type 0: a start mark at slot and an end mark at slot + len (both inside one partition, len < 2^13: a longer
+            //           range inside a wide partition goes as two keys as well)
             //   type 1: a start mark only (the read adds no coverage, or its end mark lies in another partition)
             //   type 2: an end mark only (the other half of such a read)
             // The keys leave in RECORD order (neighbouring records mostly hit the same row, so the partition path
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             uint32_t c = 0;
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
-                two[j] = hB[j] && (sA[j] >> E.log_w) != (sB[j] >> E.log_w);
+                two[j] = hB[j] && ((sA[j] >> E.log_w) != (sB[j] >> E.log_w) || (E.log_w > ITX_LOGW && sB[j] - sA[j] >= (1u << ITX_LOGW)));
                 c += (hit[j] >= 0 ? 1u : 0u) + (two[j] ? 1u : 0u);
             }
             uint32_t inc = c;                                                    // inclusive prefix sum over the lanes

@@ -299,3 +299,53 @@ def test_hot_partition_split_items_vs_oracle():
         eres, ores, hits = ec.run_both(rows, cs, rl, 1, 1, {}, [0], rd, batch_capacity=n, accum=accum)
         ec.assert_same(eres, ores, hits, False, n_rows)
         assert int(eres["cnt"][9]) > 4 * 65_535                                  # far more keys than one item holds
+
+
+def _long_consensus_case(seed, n_names, rep_len, n_rows, n_reads, long_frac):
+    """Rows of a few hundred bases and (long_frac of them) of 9-25 kb on one chromosome, consensus ranges as long as the rows;
+    reads of 36-150 bases and fragments of 9-20 kb (coverage ranges of more than 8192 slots)."""
+    rng = np.random.default_rng(seed)
+    size = 120_000_000
+    start = np.unique(rng.integers(0, size - 40_000, n_rows) // 30_000) * 30_000            # disjoint, 30 kb apart
+    n_rows = len(start)
+    is_long = rng.random(n_rows) < long_frac
+    length = np.where(is_long, rng.integers(9_000, 25_000, n_rows), rng.integers(200, 900, n_rows))
+    end = start + length
+    rep = rng.integers(0, n_names, n_rows).astype(np.int32)
+    cons_start = np.array([rng.integers(0, max(1, rep_len - int(l))) for l in length], np.int64)
+    cons_end = cons_start + length
+    z = np.zeros(n_rows, np.int32)
+    rows = eng.make_rows(z, start, end, cons_start, cons_end, rep, rep % 7, rep % 3)
+    pick = rng.integers(0, n_rows, n_reads)
+    frag = rng.random(n_reads) < 0.15
+    pos = (start[pick] + rng.integers(-100, 400, n_reads)).clip(0).astype(np.int32)
+    ln = np.where(frag & is_long[pick], rng.integers(9_000, 20_000, n_reads), rng.integers(36, 151, n_reads))
+    order = np.argsort(pos, kind="stable")
+    pos, ln = pos[order], ln[order]
+    rd = dict(tid=np.zeros(n_reads, np.int32), pos=pos, tmpend=(pos + ln).astype(np.int32),
+              mapq=rng.choice(np.array([0, 3, 20, 60], np.uint8), n_reads), flag=np.where(rng.random(n_reads) < 0.5, 16, 0).astype(np.uint16),
+              mpos=np.zeros(n_reads, np.int32), isize=np.zeros(n_reads, np.int32))
+    return rows, np.array([size], np.int64), np.full(n_names, rep_len, np.uint32), rd, n_rows
+
+
+@pytest.mark.parametrize("log_w", [14, 15, 16])
+def test_wide_partitions_vs_oracle(log_w, monkeypatch):
+    """Partitions of 2^14 .. 2^16 slots (k_hist walks a partition's LDS windows one after the other; k_stream cuts a coverage
+    range of 8192 slots or more into two keys even inside one partition) forced on a small slot space, against the oracle."""
+    monkeypatch.setenv("ITX_PART_LOGW", str(log_w))
+    rows, cs, rl, rd, n_rows = _long_consensus_case(40 + log_w, 40, 30_000, 3000, 200_000, 0.3)
+    eres, ores, hits = ec.run_both(rows, cs, rl, 7, 3, {}, [0], rd, batch_capacity=len(rd["pos"]), accum=eng.ACCUM_PARTITION)
+    ec.assert_same(eres, ores, hits, False, n_rows)
+    assert int(eres["cnt"][9]) > 150_000
+
+
+def test_slot_space_of_40M_takes_the_partition_path_vs_oracle():
+    """5000 names x 8001 consensus slots = 40 M slots: more than 4096 windows of 8192. An explicit ITX_ACCUM_PARTITION request
+    used to fail here (and the default fell back to device atomics); now the partitions are two windows wide. Against the
+    oracle, and the default path gives the same."""
+    rows, cs, rl, rd, n_rows = _long_consensus_case(77, 5000, 8000, 4000, 300_000, 0.0)
+    eres, ores, hits = ec.run_both(rows, cs, rl, 7, 3, {}, [0], rd, batch_capacity=len(rd["pos"]), accum=eng.ACCUM_PARTITION)
+    ec.assert_same(eres, ores, hits, False, n_rows)
+    dres, _, _ = ec.run_both(rows, cs, rl, 7, 3, {}, [0], rd, batch_capacity=len(rd["pos"]), accum=eng.ACCUM_DEFAULT)
+    for k in ("cnt", "cov", "cov_uniq"):
+        assert np.array_equal(np.asarray(eres[k]), np.asarray(dres[k])), k

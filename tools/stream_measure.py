@@ -22,10 +22,16 @@ def one(n_reads, steps):
     chroms = synth.HG38_CHROMS
     tb = synth.make_table(20260101, chroms, 5_500_000, n_names=15000, n_fams=60, n_clas=20, overlap_frac=0.02)
     rep_len = np.array([tb.rep_len.get(n, 0) for n in tb.names], np.uint32)
+    # ITX_MEASURE_SLOTS=<n>: consensus lengths scaled up to about n slots in all (the slot-space limit of the partition path);
+    # ITX_MEASURE_ACCUM=atomic|partition: the accumulate path asked for
+    want_slots = int(os.environ.get("ITX_MEASURE_SLOTS", "0"))
+    if want_slots:
+        rep_len = (rep_len.astype(np.float64) * (want_slots / float(rep_len.sum() + len(rep_len)))).astype(np.uint32)
+    accum = {"atomic": eng.ACCUM_ATOMIC, "partition": eng.ACCUM_PARTITION}.get(os.environ.get("ITX_MEASURE_ACCUM", ""), eng.ACCUM_DEFAULT)
     rows = eng.make_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
     cs = np.array([s for _, s in chroms], np.int64)
     table = eng.Table(rows, cs, rep_len, len(tb.fams), len(tb.clas))
-    e = eng.Engine(table, {}, batch_capacity=n_reads)
+    e = eng.Engine(table, {"accum": accum}, batch_capacity=n_reads)
     e.set_tidmap(list(range(len(chroms))))
     d = synth.make_reads_device(20260102, chroms, n_reads, dev)
     ptrs = {k: v.data_ptr() for k, v in d.items()}
@@ -39,7 +45,7 @@ def one(n_reads, steps):
     e.sync()
     s = e.stats()
     res = e.finish()
-    out = {"lib": os.environ.get("ITX_LIB", "default"), "n": n_reads, "stream_ms": s["stage_ms"][0] / s["submits"], "scatter_ms": s["stage_ms"][2] / s["submits"],
+    out = {"lib": os.environ.get("ITX_LIB", "default"), "n": n_reads, "slots": int(rep_len.sum() + len(rep_len)), "kernel_ms_per_submit": s["kernel_ms"] / s["submits"], "stream_ms": s["stage_ms"][0] / s["submits"], "scatter_ms": s["stage_ms"][2] / s["submits"],
            "hist_ms": s["stage_ms"][3] / s["submits"], "keys": s["keys"] // s["submits"], "cnt9": int(res["cnt"][9]) // steps,
            "covsum": int(res["cov"].astype(np.uint64).sum()) // steps}
     print("RESULT " + json.dumps(out), flush=True)

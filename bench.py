@@ -339,9 +339,12 @@ def main():
     t1 = time.perf_counter()
     last = None
     step_walls = []
+    slowest = None
     for k in range(a.steps):
         last = one_run(weak_list, "step", k)
         step_walls.append(round(last[0], 3))
+        if slowest is None or last[0] > slowest[0]:
+            slowest = last
         if world > 1:
             dist.barrier()
     fence()
@@ -394,6 +397,7 @@ def main():
             "step_wall_s": {"each": step_walls, "median": sorted(step_walls)[len(step_walls) // 2], "min": min(step_walls),
                             "note": "rank 0's wall of every timed step; `value` is the mean over all of them (boxes of the pool differ: on some a run loses a second or more in device allocations)"},
             "phases_last_step": phases,
+            "phases_slowest_step": [ln for ln in slowest[1].split("\n") if ln.startswith("[itx timing]")] if slowest is not last else "the last step",
             "checks": checks,
             "inputs": info,
         }

@@ -12,6 +12,16 @@
 #define ITXI_FN static __device__ inline
 #define ITXI_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(x)))
 #define ITXI_BCAST(v, j) ((uint32_t)__builtin_amdgcn_readlane((int32_t)(v), (int32_t)(j)))
+static __device__ inline uint32_t itxi_scan_add(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int32_t)v, o, 64);
+        v += lane >= (uint32_t)o ? t : 0u;
+    }
+    return v;
+}
+#define ITXI_SCAN_ADD(v, lane) itxi_scan_add(v, lane)
 #define ITXI_AT(p, i) (p)[(i) * 64u + ln]          /* a decoder's table element i: lane-interleaved (bank = lane) */
 #define ITXI_BITREV32(x) __builtin_bitreverse32(x)
 typedef uint16_t itxi_u16x2 __attribute__((ext_vector_type(2)));
@@ -72,7 +82,8 @@ __global__ __launch_bounds__(64) void k_resolve(const itx_bgzf_block *__restrict
                                                 const uint32_t *__restrict__ tok, const uint32_t *__restrict__ meta, uint8_t *__restrict__ out,
                                                 uint8_t *__restrict__ status)
 {
-    __shared__ uint32_t s_ring[ITXI_RING / 4], s_stage[ITXI_LSTAGE / 4];
+    __shared__ uint32_t s_mem[(ITXI_RING + ITXI_LSTAGE) / 4];           // the ring, and right behind it the literal stage
+    uint32_t *s_ring = s_mem, *s_stage = s_mem + ITXI_RING / 4;
     if (blockIdx.x >= n) return;
     const uint32_t b = first + blockIdx.x;
     int rc = (int)meta[3 * b];
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(RES_WAVES * 64u) void k_resolve_p(const itx_bgzf_bl
                                                                const uint32_t *__restrict__ tok, const uint32_t *__restrict__ meta, uint8_t *__restrict__ out,
                                                                uint8_t *__restrict__ status, uint32_t *__restrict__ next)
 {
-    __shared__ uint32_t s_ring[RES_WAVES][ITXI_RING / 4], s_stage[RES_WAVES][ITXI_LSTAGE / 4];
+    __shared__ uint32_t s_mem[RES_WAVES][(ITXI_RING + ITXI_LSTAGE) / 4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     (void)next;
     const uint32_t stride = gridDim.x * RES_WAVES;
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(RES_WAVES * 64u) void k_resolve_p(const itx_bgzf_bl
     for (uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(blockIdx.x * RES_WAVES + wv)); b < n; b += stride) {
         int rc = (int)meta[3 * b];
         if (rc == ITXI_OK)
-            rc = itxi_resolve(s_ring[wv], s_stage[wv], lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, meta[3 * b + 1], meta[3 * b + 2], out, blk[b].uoff,
+            rc = itxi_resolve(s_mem[wv], s_mem[wv] + ITXI_RING / 4, lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, meta[3 * b + 1], meta[3 * b + 2], out, blk[b].uoff,
                               blk[b].usize, lane);
         if (lane == 0) status[b] = (uint8_t)rc;
     }

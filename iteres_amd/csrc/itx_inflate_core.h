@@ -29,7 +29,7 @@
 // ITXI_UNI(x) (pass 2: a wave-uniform value as such), ITXI_AT(p, i) (pass 1: element i of a per-decoder table: lane-
 // interleaved on the device, using the lane id `ln` in scope), ITXI_BCAST(v, j) (pass 2: lane j's v, for all),
 // ITXI_BITREV32(x), ITXI_PKSIGN16(a, b) (bit 15 of a - b in each 16-bit half, moved to bits 0 and 16), ITXI_LOADW / ITXI_LOADB
-// (global loads), ITXI_FENCE().
+// (global loads), ITXI_FENCE(), ITXI_SCAN_ADD(v, lane) (pass 2: inclusive prefix sum of v over the lanes).
 #pragma once
 #include <stdint.h>
 
@@ -491,6 +491,22 @@ struct ItxiLit {
     uint32_t base, n_lit;                  // stage32 holds lit[base, base + ITXI_LSTAGE) as far as it exists; base % 16 == 0
 };
 
+// the stage refilled so that it starts at (the 16-byte line of) literal `at`; at < n_lit: there is something to stage
+ITXI_FN void itxi_stage_fill(ItxiLit &L, uint32_t at, uint32_t lane)
+{
+    L.base = at & ~15u;
+    uint32_t have = L.n_lit - L.base;
+    if (have > ITXI_LSTAGE) have = ITXI_LSTAGE;
+    for (uint32_t k = lane * 16u; k < have; k += ITXI_WAVE * 16u) {                // reads up to 15 bytes past n_lit: inside the block's scratch
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(L.lit + L.base + k);
+        const uint32_t a = ITXI_LOADW(src, 0), b = ITXI_LOADW(src, 1), c = ITXI_LOADW(src, 2), d = ITXI_LOADW(src, 3);
+        L.stage32[k / 4] = a;
+        L.stage32[k / 4 + 1] = b;
+        L.stage32[k / 4 + 2] = c;
+        L.stage32[k / 4 + 3] = d;
+    }
+}
+
 // n literal bytes lit[lp, lp + n) into the ring, a stripe's worth at a time so the ring never laps itself. The literals
 // come through an LDS stage refilled 4 KiB at a time: one global round trip per few hundred tokens instead of one each.
 ITXI_FN void itxi_literals(uint32_t *ring32, ItxiOut &o, ItxiLit &L, uint32_t lp, uint32_t n, uint32_t lane)
@@ -503,19 +519,7 @@ ITXI_FN void itxi_literals(uint32_t *ring32, ItxiOut &o, ItxiLit &L, uint32_t lp
         const uint32_t room = ITXI_STRIPE - (o.gp & (ITXI_STRIPE - 1u));
         if (m > room) m = room;
         const uint32_t at = lp + done;
-        if (at < L.base || at + m > L.base + ITXI_LSTAGE) {
-            L.base = at & ~15u;
-            uint32_t have = L.n_lit - L.base;                      // at < n_lit: there is something to stage
-            if (have > ITXI_LSTAGE) have = ITXI_LSTAGE;
-            for (uint32_t k = lane * 16u; k < have; k += ITXI_WAVE * 16u) {        // reads up to 15 bytes past n_lit: inside the block's scratch
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(L.lit + L.base + k);
-                const uint32_t a = ITXI_LOADW(src, 0), b = ITXI_LOADW(src, 1), c = ITXI_LOADW(src, 2), d = ITXI_LOADW(src, 3);
-                L.stage32[k / 4] = a;
-                L.stage32[k / 4 + 1] = b;
-                L.stage32[k / 4 + 2] = c;
-                L.stage32[k / 4 + 3] = d;
-            }
-        }
+        if (at < L.base || at + m > L.base + ITXI_LSTAGE) itxi_stage_fill(L, at, lane);
         for (uint32_t k = lane; k < m; k += ITXI_WAVE) ring8[(o.gp + k) & ITXI_MASK] = stage8[at - L.base + k];
         o.gp += m;
         done += m;
@@ -524,7 +528,8 @@ ITXI_FN void itxi_literals(uint32_t *ring32, ItxiOut &o, ItxiLit &L, uint32_t lp
 }
 
 // Replays a block's tokens (validated by pass 1: distances inside the block, lengths inside usize) into out[g0, g0 + usize).
-// Tokens are fetched a wave's width at a time, one per lane, the next batch while the current one is replayed.
+// Tokens are fetched a wave's width at a time, one per lane, the next batch while the current one is replayed. stage32 must
+// lie right behind the ring (ring32 + ITXI_RING / 4).
 ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit, const uint32_t *tok, uint32_t n_lit, uint32_t n_tok, uint8_t *out, uint32_t g0,
                          uint32_t usize, uint32_t lane)
 {
@@ -542,6 +547,7 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
     L.n_lit = n_lit;
     uint32_t lp = 0;
     if (n_lit > usize || n_tok > ITXI_MAX_TOK) return ITXI_E_OUTPUT;
+    if (reinterpret_cast<const uint8_t *>(stage32) != ring8 + ITXI_RING) return ITXI_E_OUTPUT;      // the short step reads both through ring8
     uint32_t nx = 0, nd = 0;
     if (lane < n_tok) {
         nx = ITXI_LOADW(tok, 2 * lane);
@@ -555,15 +561,58 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
             nd = ITXI_LOADW(tok, 2 * tn + 1);
         }
         const uint32_t nb = n_tok - t0 < ITXI_WAVE ? n_tok - t0 : ITXI_WAVE;
+        // Per token, in the lanes (lane j = token j of the batch): where its bytes go and where its literals come from (prefix
+        // sums), and whether the SHORT STEP may take it — literals and match together no longer than a wave, the match's source
+        // entirely before the token's own bytes, every guard of the long way round satisfied. The serial
+        // loop below is bound by the CU's scalar unit (measured: 65 scalar instructions per token, the scalar pipe shared by
+        // four SIMDs); what can be worked out for 64 tokens at once in the vector pipes is.
+        const bool have = lane < nb;
+        const uint32_t v_run = have ? cx & 0xffffu : 0u, v_len = have ? cx >> 16 : 0u, v_tot = v_run + v_len;
+        const uint32_t e_gp = ITXI_SCAN_ADD(v_tot, lane), e_lp = ITXI_SCAN_ADD(v_run, lane);           // inclusive
+        const uint32_t v_gp = o.gp + e_gp - v_tot, v_lp = lp + e_lp - v_run;
+        const uint32_t lit_total = ITXI_BCAST(e_lp, ITXI_WAVE - 1u);
+        // the batch's literals staged all at once when they fit (they nearly always do): no refill inside the batch
+        bool staged = false;
+        if (lit_total <= ITXI_LSTAGE - 16u && lp + lit_total <= n_lit) {
+            if (lit_total && (lp < L.base || lp + lit_total > L.base + ITXI_LSTAGE)) itxi_stage_fill(L, lp, lane);
+            staged = true;
+        }
+        const bool v_fast = have && staged && v_len >= 3u && v_len <= 258u && v_tot <= ITXI_WAVE && cd >= v_tot &&
+                            v_gp + v_tot <= o.gend && cd <= v_gp + v_run - o.g0;
+        const uint32_t v_rt = v_fast ? v_run | (v_tot << 16) | 0x80000000u : 0u;        // v_tot <= 64 there
+        const uint32_t v_ls = v_lp - L.base;                       // the literals' place in the stage (meaningful when staged)
         for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t rt = ITXI_BCAST(v_rt, j);
+            if (rt & 0x80000000u) {
+                // the short step: one byte per lane, literals from the stage, match bytes from the ring, one store each
+                const uint32_t g = ITXI_BCAST(v_gp, j), d = ITXI_BCAST(cd, j), ls = ITXI_BCAST(v_ls, j);
+                const uint32_t r = rt & 0xffffu, tt = (rt >> 16) & 0x7fffu;
+                if (d <= ITXI_NEAR) {
+                    if (lane < tt) {
+                        // one load whichever the source: the stage lies right behind the ring (checked above)
+                        const uint32_t from = lane < r ? ITXI_RING + ls + lane : (g + lane - d) & ITXI_MASK;
+                        ring8[(g + lane) & ITXI_MASK] = ring8[from];
+                    }
+                } else {
+                    // the match reaches further back than the ring: those bytes left in whole stripes long ago
+                    ITXI_FENCE();
+                    if (lane < tt) {
+                        uint8_t b;
+                        if (lane < r) b = ring8[ITXI_RING + ls + lane];
+                        else b = ITXI_LOADB(o.g, g + lane - d);
+                        ring8[(g + lane) & ITXI_MASK] = b;
+                    }
+                }
+                o.gp = g + tt;
+                itxi_flush_full(ring32, o, lane);
+                continue;
+            }
             const uint32_t x = ITXI_BCAST(cx, j), dist = ITXI_BCAST(cd, j);
             const uint32_t run = x & 0xffffu, len = x >> 16;
+            const uint32_t lpj = ITXI_BCAST(v_lp, j);              // == lp + the runs of the batch's tokens before this one
             // guards that hold for every token pass 1 lets through; they keep a damaged token array from leaving the block
-            if (run > n_lit - lp || run + len > o.gend - o.gp || len < 3u || len > 258u) return ITXI_E_OUTPUT;
-            if (run) {
-                itxi_literals(ring32, o, L, lp, run, lane);
-                lp += run;
-            }
+            if (lpj > n_lit || run > n_lit - lpj || run + len > o.gend - o.gp || len < 3u || len > 258u) return ITXI_E_OUTPUT;
+            if (run) itxi_literals(ring32, o, L, lpj, run, lane);
             if (dist == 0 || dist > o.gp - o.g0) return ITXI_E_DIST;
             const uint32_t src0 = o.gp - dist;
             if (dist <= ITXI_NEAR) {
@@ -591,6 +640,7 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
             o.gp += len;
             itxi_flush_full(ring32, o, lane);
         }
+        lp += lit_total;
     }
     const uint32_t tail = n_lit - lp;
     if (tail != o.gend - o.gp) return ITXI_E_OUTPUT;

@@ -7,6 +7,7 @@
 #define ITXI_FN static inline
 #define ITXI_UNI(x) (x)
 #define ITXI_BCAST(v, j) (v)
+#define ITXI_SCAN_ADD(v, lane) (v)
 static inline uint32_t itxi_bitrev32(uint32_t x)
 {
     x = (x >> 16) | (x << 16);
@@ -34,7 +35,8 @@ extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, u
     static thread_local uint16_t offs[16], loffs[16], doffs[16];
     static thread_local uint8_t lsym8[288], dsym[32], lens[176];
     static thread_local uint32_t lhi[9];
-    static thread_local uint32_t ring32[ITXI_RING / 4], stage32[ITXI_LSTAGE / 4];
+    static thread_local uint32_t mem32[(ITXI_RING + ITXI_LSTAGE) / 4];       // the literal stage right behind the ring (itxi_resolve's contract)
+    uint32_t *ring32 = mem32, *stage32 = mem32 + ITXI_RING / 4;
     static thread_local std::vector<uint32_t> lit32(ITXI_MAX_BLOCK / 4 + 4);
     uint8_t *lit = reinterpret_cast<uint8_t *>(lit32.data());
     static thread_local std::vector<uint32_t> tok(2 * ITXI_MAX_TOK);

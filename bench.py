@@ -66,8 +66,48 @@ def parse_args():
     ap.add_argument("--threads", type=int, default=0, help="host threads of the command (0: min(16, cores))")
     ap.add_argument("--workdir", default=os.environ.get("ITX_BENCH_DIR", ""))
     ap.add_argument("--keep", action="store_true", help="keep the generated inputs (they are reused when present)")
+    ap.add_argument("--no-settle", action="store_true", help="skip the device-memory warm-up (see vram_settle)")
     ap.add_argument("--no-replay-check", action="store_true", help="profiling runs: skip the small oracle-checked launch, so that every k_stream launch of this process has the replay's size")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ device memory
+SETTLE_CHILD = r'''
+import os, sys, time, torch
+dev = int(sys.argv[1]); want = float(sys.argv[2])
+torch.cuda.set_device(dev)
+free, total = torch.cuda.mem_get_info()
+goal = min(want * (1 << 30), 0.8 * free)
+keep, got, t0, slow = [], 0, time.perf_counter(), 0.0
+while got < goal:
+    t1 = time.perf_counter()
+    keep.append(torch.empty(8 << 30, dtype=torch.uint8, device="cuda")); torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    slow += dt if dt > 0.05 else 0.0
+    got += 8 << 30
+print(f"{got / (1 << 30):.0f} {time.perf_counter() - t0:.3f} {slow:.3f}", flush=True)
+os._exit(0)
+'''
+
+
+def vram_settle(device, gb=176.0, pause=6.0):
+    """A fresh box hands out device memory the driver has yet to clear: the first allocations of tens of GB then take
+    1.3 - 2.2 s per 50 GB (tools/release_cost.py; memory a process released is cleared in the background and comes back at
+    once). The command allocates ~50 GB per run, so on such a box the first runs lose seconds inside hipMalloc — box state,
+    not the command's. Before anything is timed (and before the minutes of input generation) a child process takes and
+    releases most of the card once; what it found is reported in the JSON line (`vram_settle`)."""
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run([sys.executable, "-c", SETTLE_CHILD, str(device), str(gb)], capture_output=True, text=True, timeout=120)
+        f = out.stdout.split()
+        res = {"allocated_GB": float(f[0]), "seconds": float(f[1]), "seconds_in_slow_allocations": float(f[2])}
+    except Exception as e:                                                    # never fatal: it is only a warm-up
+        res = {"error": str(e)[:200]}
+    if res.get("seconds_in_slow_allocations", 0) > 0.5:
+        time.sleep(pause)                                                     # the release is cleared in the background
+    res["total_s"] = round(time.perf_counter() - t0, 2)
+    res["what"] = "one child process allocated and released this much device memory before inputs, warm-up and timed steps (bench.py vram_settle)"
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ inputs (rank 0)
@@ -293,6 +333,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ---------------------------------------------------------------- device memory settled before anything is timed
+    settle = vram_settle(local_rank) if not a.no_settle else None
+
     # ---------------------------------------------------------------- inputs: rank 0 makes them, everybody learns where
     box = [None, None]
     if rank == 0:
@@ -396,6 +439,7 @@ def main():
                           "M_alignments_per_s": round(a.reads * world / scan_s / 1e6, 2) if scan_s else None},
             "step_wall_s": {"each": step_walls, "median": sorted(step_walls)[len(step_walls) // 2], "min": min(step_walls),
                             "note": "rank 0's wall of every timed step; `value` is the mean over all of them (boxes of the pool differ: on some a run loses a second or more in device allocations)"},
+            "vram_settle": settle,
             "phases_last_step": phases,
             "phases_slowest_step": [ln for ln in slowest[1].split("\n") if ln.startswith("[itx timing]")] if slowest is not last else "the last step",
             "checks": checks,

@@ -228,17 +228,23 @@ def test_unit_and_window_shapes(accum):
         ec.assert_same(eres, ores, hits, False, n)
     assert (ores["hit_row"] >= 0).mean() > 0.3 and int(ores["cov"].astype(np.uint64).sum()) > 1_000_000
     if accum == eng.ACCUM_PARTITION:
-        # a slot space beyond the partition path's 4096 windows: asked for explicitly it is refused, by default the
-        # engine takes the atomics path and gives the same sums
+        # a slot space beyond 4096 windows of 8192 (210 M slots): the partitions become 2^16 slots wide, k_hist walks their
+        # eight windows in turn; same sums as the oracle, asked for explicitly and by default
         big = np.full(n_names, 70_000, np.uint32)
-        t = eng.Table(rows, [size], big, 50, 9)
-        with pytest.raises(eng.ItxError):
-            eng.Engine(t, dict(accum=eng.ACCUM_PARTITION), batch_capacity=1000)
-        t.close()
         k = 60_000
         sub = {key: v[:k] for key, v in rd.items()}
-        eres, ores, hits = ec.run_both(rows, [size], big, 50, 9, dict(), [0], sub, batch_capacity=20_000, accum=eng.ACCUM_DEFAULT)
-        ec.assert_same(eres, ores, hits, False, n)
+        for how in (eng.ACCUM_PARTITION, eng.ACCUM_DEFAULT):
+            eres, ores, hits = ec.run_both(rows, [size], big, 50, 9, dict(), [0], sub, batch_capacity=20_000, accum=how)
+            ec.assert_same(eres, ores, hits, False, n)
+        # beyond 4096 x 2^16 slots the partition path is refused when asked for explicitly (the default then takes the
+        # atomics path: same sums, slower)
+        huge = np.full(n_names, 90_000, np.uint32)                      # 270 M slots
+        t = eng.Table(rows, [size], huge, 50, 9)
+        with pytest.raises(eng.ItxError):
+            eng.Engine(t, dict(accum=eng.ACCUM_PARTITION), batch_capacity=1000)
+        e = eng.Engine(t, dict(accum=eng.ACCUM_DEFAULT), batch_capacity=1000)
+        e.close()
+        t.close()
 
 
 def test_long_spans_few_workgroups(monkeypatch):

@@ -334,7 +334,7 @@ def main():
             torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- device memory settled before anything is timed
-    settle = vram_settle(local_rank) if not a.no_settle else None
+    settle = None if a.no_settle or os.environ.get("ITX_BENCH_SHARE_GPU") == "1" else vram_settle(local_rank)      # (ranks sharing one card would fight over it)
 
     # ---------------------------------------------------------------- inputs: rank 0 makes them, everybody learns where
     box = [None, None]

@@ -122,7 +122,9 @@ static void *warm_main(void *arg)
     const double a = now_s();
     const int ndev = itx_device_count();
     const double b = now_s();
+    double t_created = b, t_pinned = b;
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(multi_device(), &g_inflater) == ITX_OK) {
+        t_created = now_s();
         /* the compressed chunks the reader rotates through (one being read, the others being decoded) */
         const char *ce = getenv("ITX_BGZF_CHUNK");
         const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
@@ -133,6 +135,7 @@ static void *warm_main(void *arg)
             pool[i].p = itx_pinned_alloc(want[i]);
             pool[i].cap = pool[i].p ? want[i] : 0;
         }
+        t_pinned = now_s();
         /* the device side of the decoder, all of it, now that nothing runs there yet: windows and per-push scratch sized for
          * the most a push may carry (the block indexer cuts a chunk that inflates to more into two pushes) */
         const char *be = getenv("ITX_DEV_WINDOW_BLOCKS");
@@ -173,8 +176,8 @@ static void *warm_main(void *arg)
         if (warm_reader) aln_readahead(warm_reader);
     }
     if (getenv("ITX_TIMING"))
-        fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s, device inflater + page-locked buffers %.3f s, first file opened %.3f s (helper thread)\n", b - a,
-                c - b, now_s() - c);
+        fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s, device inflater + page-locked buffers %.3f s (streams %.3f, page-locked %.3f, device reserve %.3f), first file opened %.3f s (helper thread)\n", b - a,
+                c - b, t_created - b, t_pinned - t_created, c - t_pinned, now_s() - c);
     return NULL;
 }
 void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file, int splittable)

@@ -393,9 +393,15 @@ static void *io_main(void *arg)
             const size_t step = RAW_STEP;
             size_t want = r->io_size > r->io_off ? r->io_size - r->io_off : 0;
             if (want > step) want = step;
-            const int parts = want >= (4u << 20) ? 4 : 1;
+            static int max_parts;                                   /* ITX_READ_PARTS (1..16) overrides */
+            if (!max_parts) {
+                const char *e = getenv("ITX_READ_PARTS");
+                const int v = e ? atoi(e) : 0;
+                max_parts = v >= 1 && v <= 16 ? v : 4;
+            }
+            const int parts = want >= (4u << 20) ? max_parts : 1;
             const size_t per = (want + (size_t)parts - 1) / (size_t)parts;
-            size_t done[4] = {0, 0, 0, 0};
+            size_t done[16] = {0};
 #pragma omp parallel for num_threads(parts) schedule(static, 1)
             for (int q = 0; q < parts; q++) {
                 const size_t lo = (size_t)q * per, hi = lo + per < want ? lo + per : want;

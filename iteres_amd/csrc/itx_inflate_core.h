@@ -579,30 +579,37 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
         }
         const bool v_fast = have && staged && v_len >= 3u && v_len <= 258u && v_tot <= ITXI_WAVE && cd >= v_tot &&
                             v_gp + v_tot <= o.gend && cd <= v_gp + v_run - o.g0;
-        const uint32_t v_rt = v_fast ? v_run | (v_tot << 16) | 0x80000000u : 0u;        // v_tot <= 64 there
+        // bit 31: the short step with the match inside the ring, bit 30: with the match further back (v_tot <= 64 there)
+        const uint32_t v_rt = v_fast ? v_run | (v_tot << 16) | (cd <= ITXI_NEAR ? 0x80000000u : 0x40000000u) : 0u;
         const uint32_t v_ls = v_lp - L.base;                       // the literals' place in the stage (meaningful when staged)
+        // the two addresses a lane reads in a short step, less the token's own offsets: stage byte / ring byte of ITS place
         for (uint32_t j = 0; j < nb; j++) {
             const uint32_t rt = ITXI_BCAST(v_rt, j);
-            if (rt & 0x80000000u) {
-                // the short step: one byte per lane, literals from the stage, match bytes from the ring (or, far back, from
-                // what was written out long ago), one store each. (Taking longer tokens this way too, 64 bytes a step, was
-                // measured slower: 15.4 ms instead of 13.0 per 24 k blocks — the literal runs of the long way round move a
-                // stripe per flush check.)
+            if ((int32_t)rt < 0) {
+                // the short step: one byte per lane, literals from the stage, match bytes from the ring, one store each.
+                // EVERY lane stores: the lanes past the token's end put a stale byte where a later token will put the right
+                // one before anything reads or writes it back — what they overwrite in the ring lies a whole ring behind, out
+                // of any match's reach (ITXI_NEAR) and written back long ago. (Taking longer tokens this way too, 64 bytes a
+                // step, was measured slower: 15.4 ms instead of 13.0 per 24 k blocks — the literal runs of the long way round
+                // move a stripe per flush check.)
                 const uint32_t g = ITXI_BCAST(v_gp, j), d = ITXI_BCAST(cd, j), ls = ITXI_BCAST(v_ls, j);
-                const uint32_t r = rt & 0xffffu, tt = (rt >> 16) & 0x7fffu;
-                if (d <= ITXI_NEAR) {
-                    // one load whichever the source: the stage lies right behind the ring (checked above)
-                    const uint32_t a_lit = ITXI_RING + ls + lane, a_ring = (g + lane - d) & ITXI_MASK;
-                    const uint32_t from = a_ring ^ ((a_ring ^ a_lit) & (0u - (uint32_t)(lane < r)));
-                    if (lane < tt) ring8[(g + lane) & ITXI_MASK] = ring8[from];
-                } else {
-                    // the match reaches further back than the ring: those bytes left in whole stripes long ago
-                    // (two statements, not one load through a selected pointer: that would be a flat load, and the compiler
-                    // would fold the near branch above into it as well)
-                    ITXI_FENCE();
-                    if (lane < r) ring8[(g + lane) & ITXI_MASK] = ring8[ITXI_RING + ls + lane];
-                    else if (lane < tt) ring8[(g + lane) & ITXI_MASK] = ITXI_LOADB(o.g, g + lane - d);
-                }
+                const uint32_t r = rt & 0xffffu;
+                // one load whichever the source: the stage lies right behind the ring (checked above)
+                const uint32_t a_lit = ITXI_RING + ls + lane, a_ring = (g + lane - d) & ITXI_MASK;
+                const uint32_t from = a_ring ^ ((a_ring ^ a_lit) & (0u - (uint32_t)(lane < r)));
+                ring8[(g + lane) & ITXI_MASK] = ring8[from];
+                o.gp = g + ((rt >> 16) & 0xffu);
+                itxi_flush_full(ring32, o, lane);
+                continue;
+            }
+            if (rt & 0x40000000u) {
+                // the same with a match that reaches further back than the ring: those bytes left in whole stripes long ago
+                // (two statements, not one load through a selected pointer: that would be a flat load)
+                const uint32_t g = ITXI_BCAST(v_gp, j), d = ITXI_BCAST(cd, j), ls = ITXI_BCAST(v_ls, j);
+                const uint32_t r = rt & 0xffffu, tt = (rt >> 16) & 0xffu;
+                ITXI_FENCE();
+                if (lane < r) ring8[(g + lane) & ITXI_MASK] = ring8[ITXI_RING + ls + lane];
+                else if (lane < tt) ring8[(g + lane) & ITXI_MASK] = ITXI_LOADB(o.g, g + lane - d);
                 o.gp = g + tt;
                 itxi_flush_full(ring32, o, lane);
                 continue;

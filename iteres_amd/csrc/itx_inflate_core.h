@@ -45,6 +45,7 @@
 #define ITXI_MASK (ITXI_RING - 1u)
 #define ITXI_STRIPE 256u                   // write-back granule: 64 lanes x 4 bytes
 #define ITXI_NEAR (ITXI_RING - 320u)       // matches up to this distance read the ring (a match writes at most 258 bytes ahead)
+#define ITXI_LAG 1024u                     // pass 2: full stripes may wait this long for their write-back (+ a stripe + a token < ITXI_NEAR - 258)
 #define ITXI_MAX_BLOCK 65536u              // BGZF: a block inflates to at most 64 KiB
 #define ITXI_MAX_TOK (ITXI_MAX_BLOCK / 3u + 1u)       // a match is at least 3 bytes
 
@@ -584,21 +585,29 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
         const uint32_t v_ls = v_lp - L.base;                       // the literals' place in the stage (meaningful when staged)
         // the two addresses a lane reads in a short step, less the token's own offsets: stage byte / ring byte of ITS place
         for (uint32_t j = 0; j < nb; j++) {
-            const uint32_t rt = ITXI_BCAST(v_rt, j);
+            uint32_t rt = ITXI_BCAST(v_rt, j);
             if ((int32_t)rt < 0) {
                 // the short step: one byte per lane, literals from the stage, match bytes from the ring, one store each.
                 // EVERY lane stores: the lanes past the token's end put a stale byte where a later token will put the right
                 // one before anything reads or writes it back — what they overwrite in the ring lies a whole ring behind, out
-                // of any match's reach (ITXI_NEAR) and written back long ago. (Taking longer tokens this way too, 64 bytes a
-                // step, was measured slower: 15.4 ms instead of 13.0 per 24 k blocks — the literal runs of the long way round
-                // move a stripe per flush check.)
-                const uint32_t g = ITXI_BCAST(v_gp, j), d = ITXI_BCAST(cd, j), ls = ITXI_BCAST(v_ls, j);
-                const uint32_t r = rt & 0xffffu;
-                // one load whichever the source: the stage lies right behind the ring (checked above)
-                const uint32_t a_lit = ITXI_RING + ls + lane, a_ring = (g + lane - d) & ITXI_MASK;
-                const uint32_t from = a_ring ^ ((a_ring ^ a_lit) & (0u - (uint32_t)(lane < r)));
-                ring8[(g + lane) & ITXI_MASK] = ring8[from];
-                o.gp = g + ((rt >> 16) & 0xffu);
+                // of any match's reach (ITXI_NEAR) and written back long ago. Short steps that follow one another run in a
+                // loop of their own (straight-line code: the scalar pipe is what this kernel is bound by) and leave the
+                // write-back of full stripes to its end — at most ITXI_LAG bytes later, well inside what the ring keeps.
+                // (Taking longer tokens this way too, 64 bytes a step, was measured slower: 15.4 ms instead of 13.0 per 24 k
+                // blocks — the literal runs of the long way round move a stripe per flush check.)
+                for (;;) {
+                    const uint32_t g = ITXI_BCAST(v_gp, j), d = ITXI_BCAST(cd, j), ls = ITXI_BCAST(v_ls, j);
+                    const uint32_t r = rt & 0xffffu;
+                    // one load whichever the source: the stage lies right behind the ring (checked above)
+                    const uint32_t a_lit = ITXI_RING + ls + lane, a_ring = (g + lane - d) & ITXI_MASK;
+                    const uint32_t from = a_ring ^ ((a_ring ^ a_lit) & (0u - (uint32_t)(lane < r)));
+                    ring8[(g + lane) & ITXI_MASK] = ring8[from];
+                    o.gp = g + ((rt >> 16) & 0xffu);
+                    if (j + 1u >= nb || o.gp - o.fl >= ITXI_LAG) break;
+                    rt = ITXI_BCAST(v_rt, j + 1u);
+                    if ((int32_t)rt >= 0) break;
+                    j++;
+                }
                 itxi_flush_full(ring32, o, lane);
                 continue;
             }

@@ -22,6 +22,7 @@ static __device__ inline uint32_t itxi_scan_add(uint32_t v, uint32_t lane)
     return v;
 }
 #define ITXI_SCAN_ADD(v, lane) itxi_scan_add(v, lane)
+#define ITXI_NEXT(v, lane) ((lane) < 63u ? (uint32_t)__shfl_down((int32_t)(v), 1, 64) : 0u)
 #define ITXI_AT(p, i) (p)[(i) * 64u + ln]          /* a decoder's table element i: lane-interleaved (bank = lane) */
 #define ITXI_BITREV32(x) __builtin_bitreverse32(x)
 typedef uint16_t itxi_u16x2 __attribute__((ext_vector_type(2)));

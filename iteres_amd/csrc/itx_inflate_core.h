@@ -29,7 +29,8 @@
 // ITXI_UNI(x) (pass 2: a wave-uniform value as such), ITXI_AT(p, i) (pass 1: element i of a per-decoder table: lane-
 // interleaved on the device, using the lane id `ln` in scope), ITXI_BCAST(v, j) (pass 2: lane j's v, for all),
 // ITXI_BITREV32(x), ITXI_PKSIGN16(a, b) (bit 15 of a - b in each 16-bit half, moved to bits 0 and 16), ITXI_LOADW / ITXI_LOADB
-// (global loads), ITXI_FENCE(), ITXI_SCAN_ADD(v, lane) (pass 2: inclusive prefix sum of v over the lanes).
+// (global loads), ITXI_FENCE(), ITXI_SCAN_ADD(v, lane) (pass 2: inclusive prefix sum of v over the lanes), ITXI_NEXT(v, lane) (pass 2: the next
+// lane's v, 0 for the last lane).
 #pragma once
 #include <stdint.h>
 
@@ -583,6 +584,11 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
         // bit 31: the short step with the match inside the ring, bit 30: with the match further back (v_tot <= 64 there)
         const uint32_t v_rt = v_fast ? v_run | (v_tot << 16) | (cd <= ITXI_NEAR ? 0x80000000u : 0x40000000u) : 0u;
         const uint32_t v_ls = v_lp - L.base;                       // the literals' place in the stage (meaningful when staged)
+        // what lets a short step follow the one before without a look at anything else: the NEXT token's word, if that is a
+        // near short step and this token does not end in another ITXI_LAG bytes of output than it began (then the full stripes
+        // are written back first); 0 behind the batch's last token
+        const uint32_t v_nx = ITXI_NEXT(v_rt, lane);
+        const uint32_t v_rtn = ((int32_t)v_nx < 0 && ((v_gp + v_tot) ^ v_gp) < ITXI_LAG) ? v_nx : 0u;
         // the two addresses a lane reads in a short step, less the token's own offsets: stage byte / ring byte of ITS place
         for (uint32_t j = 0; j < nb; j++) {
             uint32_t rt = ITXI_BCAST(v_rt, j);
@@ -595,19 +601,19 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
                 // write-back of full stripes to its end — at most ITXI_LAG bytes later, well inside what the ring keeps.
                 // (Taking longer tokens this way too, 64 bytes a step, was measured slower: 15.4 ms instead of 13.0 per 24 k
                 // blocks — the literal runs of the long way round move a stripe per flush check.)
-                for (;;) {
-                    const uint32_t g = ITXI_BCAST(v_gp, j), d = ITXI_BCAST(cd, j), ls = ITXI_BCAST(v_ls, j);
+                uint32_t jj = j;
+                do {
+                    const uint32_t g = ITXI_BCAST(v_gp, jj), d = ITXI_BCAST(cd, jj), ls = ITXI_BCAST(v_ls, jj);
                     const uint32_t r = rt & 0xffffu;
                     // one load whichever the source: the stage lies right behind the ring (checked above)
                     const uint32_t a_lit = ITXI_RING + ls + lane, a_ring = (g + lane - d) & ITXI_MASK;
                     const uint32_t from = a_ring ^ ((a_ring ^ a_lit) & (0u - (uint32_t)(lane < r)));
                     ring8[(g + lane) & ITXI_MASK] = ring8[from];
                     o.gp = g + ((rt >> 16) & 0xffu);
-                    if (j + 1u >= nb || o.gp - o.fl >= ITXI_LAG) break;
-                    rt = ITXI_BCAST(v_rt, j + 1u);
-                    if ((int32_t)rt >= 0) break;
-                    j++;
-                }
+                    rt = ITXI_BCAST(v_rtn, jj);                    // the next token's word if it may follow at once, else 0
+                    jj++;
+                } while ((int32_t)rt < 0);
+                j = jj - 1u;
                 itxi_flush_full(ring32, o, lane);
                 continue;
             }

@@ -8,6 +8,7 @@
 #define ITXI_UNI(x) (x)
 #define ITXI_BCAST(v, j) (v)
 #define ITXI_SCAN_ADD(v, lane) (v)
+#define ITXI_NEXT(v, lane) 0u
 static inline uint32_t itxi_bitrev32(uint32_t x)
 {
     x = (x >> 16) | (x << 16);

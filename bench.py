@@ -364,11 +364,16 @@ def main():
         dist.barrier()
     weak_list = ",".join(os.path.join(wd, f"reads_copy{r}.bam") for r in range(world)) if world > 1 else bam
 
+    # a name no earlier (crashed) invocation can have left behind: the ranks of a run find each other through this file
+    nonce = [f"{os.getpid()}_{int(time.time())}"]
+    if world > 1:
+        dist.broadcast_object_list(nonce, src=0)
+
     def one_run(aln, tag, step):
         """one whole command over `aln` by all ranks; returns this rank's wall seconds and its stderr"""
         e = dict(env)
         if world > 1:
-            e.update(ITX_RANK=str(rank), ITX_WORLD=str(world), ITX_DEVICE=str(local_rank), ITX_COMM_ID=os.path.join(wd, f"comm_{tag}_{step}.id"),
+            e.update(ITX_RANK=str(rank), ITX_WORLD=str(world), ITX_DEVICE=str(local_rank), ITX_COMM_ID=os.path.join(wd, f"comm_{nonce[0]}_{tag}_{step}.id"),
                      ITX_EXCHANGE="file" if share_gpu else "rccl")
         wall, rc, err, seen = run_timed(OURS, base_args(wd) + [aln], scratch, e, (SCAN_BEGIN, SCAN_END))
         if rc != 0:

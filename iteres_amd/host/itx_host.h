@@ -213,6 +213,7 @@ int multi_rank(void);
 int multi_world(void);
 int multi_device(void);
 int multi_comm_mode(void);
+int multi_selftest(void);
 const char *multi_comm_id(void);
 /* stream.c: what the writers read — itx_engine_finish, or, after a multi-GPU stream, the same from the reduced partial */
 int stream_finish(itx_engine *eng, const itx_result *res);

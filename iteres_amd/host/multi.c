@@ -32,6 +32,7 @@ int multi_rank(void) { return g_rank; }
 int multi_world(void) { return g_world; }
 int multi_device(void) { return g_device; }
 int multi_comm_mode(void) { return g_mode; }
+int multi_selftest(void) { return g_external && g_world == 1; }      /* ITX_COMM_SELFTEST: one rank, whole exchange */
 const char *multi_comm_id(void) { return g_id; }
 
 static void quiet_rank(void)
@@ -52,7 +53,9 @@ void multi_early(int argc, char **argv)
     g_argc = argc;
     g_argv = argv;
     const char *r = getenv("ITX_RANK"), *w = getenv("ITX_WORLD");
-    if (!r || !w || atoi(w) <= 1) return;
+    /* ITX_COMM_SELFTEST with ITX_WORLD=1: a job of one rank that still walks the whole exchange (communicator made beside the
+     * scan, both reduces, finish from the reduced partial) — all of the N > 1 path a one-GPU box can run through RCCL */
+    if (!r || !w || atoi(w) < 1 || (atoi(w) == 1 && !getenv("ITX_COMM_SELFTEST"))) return;
     g_world = atoi(w);
     g_rank = atoi(r);
     if (g_rank < 0 || g_rank >= g_world || g_world > MAX_RANKS) die("ITX_RANK=%s / ITX_WORLD=%s: not a rank of a job", r, w);

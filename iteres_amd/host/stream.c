@@ -116,12 +116,31 @@ static int plan_shares(char **files, int n_files, int splittable, int rank, int 
 static int warm_splittable;
 static size_t warm_input_bytes;               /* size of all alignment files together (0: unknown) */
 
+/* The communicator of a multi-rank job is made while the stream is being read: ncclCommInitRank takes seconds (bootstrap
+ * over the network interface, one ring per link) and needs nothing of the data — the exchange at the end only joins it. */
+static struct {
+    pthread_t th;
+    int on, rc;
+    itx_comm *comm;
+    char err[400];
+} early_comm;
+static void *early_comm_main(void *arg)
+{
+    (void)arg;
+    early_comm.rc = itx_comm_create(multi_rank(), multi_world(), multi_device(), multi_comm_id(), ITX_COMM_RCCL, &early_comm.comm);
+    if (early_comm.rc != ITX_OK) snprintf(early_comm.err, sizeof early_comm.err, "%s", itx_last_error());
+    return NULL;
+}
+
 static void *warm_main(void *arg)
 {
     (void)arg;
     const double a = now_s();
     const int ndev = itx_device_count();
     const double b = now_s();
+    if (ndev > 0 && (multi_world() > 1 || multi_selftest()) && multi_comm_mode() == ITX_COMM_RCCL && !getenv("ITX_NO_EARLY_COMM") &&
+        pthread_create(&early_comm.th, NULL, early_comm_main, NULL) == 0)
+        early_comm.on = 1;
     double t_created = b, t_pinned = b;
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(multi_device(), &g_inflater) == ITX_OK) {
         t_created = now_s();
@@ -647,7 +666,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             fprintf(stderr, "[itx timing] open %.3f s, record loop %.3f s, drain %.3f s, close %.3f s\n", t_opened - t_open0, t_loop_done - t_opened,
                     t_drained - t_loop_done, now_s() - t_drained);
     }
-    if (pass == 1 || world <= 1) break;
+    if (pass == 1 || (world <= 1 && !multi_selftest())) break;
     {
         /* ---- the ONE exchange: every rank's partial, summed onto rank 0 (RCCL over xGMI) */
         const double tx = now_s();
@@ -661,11 +680,20 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         itx_comm *comm = NULL;
         const double tc = now_s();
         int comm_mode = multi_comm_mode();
-        int crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
+        int crc;
+        if (early_comm.on) {                                         /* under way since the start of the run */
+            pthread_join(early_comm.th, NULL);
+            early_comm.on = 0;
+            crc = early_comm.rc;
+            comm = early_comm.comm;
+            if (crc != ITX_OK) warnf("[iteres] note: %s", early_comm.err);
+        } else {
+            crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
+        }
         if (crc != ITX_OK && comm_mode == ITX_COMM_RCCL) {
             /* no RCCL communicator (no usable network interface for its bootstrap, say): the environment is the same for every
              * rank, so they all end up here and hand their partials over through files — slower, same sums */
-            warnf("[iteres] note: %s; the ranks exchange through files instead", itx_last_error());
+            warnf("[iteres] note: no RCCL communicator (%s); the ranks exchange through files instead", early_comm.err[0] ? early_comm.err : itx_last_error());
             comm_mode = ITX_COMM_FILE;
             crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
         }

@@ -193,3 +193,24 @@ def test_rccl_bring_up_with_one_rank(tmp_path):
         L.itx_comm_destroy(h)
     finally:
         os.environ.pop("ITX_COMM_SELFTEST", None)
+
+
+@pytest.mark.parametrize("head", [["stat", "-w"], ["filter", "-n", "Rep3"]])
+def test_command_walks_the_rccl_exchange_with_one_rank(head, exe, big_case, tmp_path):
+    """ITX_COMM_SELFTEST + ITX_WORLD=1: the command as a job of ONE rank that still makes its RCCL communicator beside the
+    scan (the early thread of host/stream.c), exports its partial, reduces it through ncclReduce and finishes from the reduced
+    buffers — the N > 1 path end to end as far as a one-GPU box can take it. Same files as the plain run."""
+    d = big_case
+    aln = str(d / "a.bam")
+    ref_dir, out = str(tmp_path / "plain"), str(tmp_path / "self")
+    _run(exe, head, d, aln, ref_dir, dict(os.environ))
+    env = dict(os.environ, ITX_RANK="0", ITX_WORLD="1", ITX_DEVICE="0", ITX_COMM_ID=str(tmp_path / "self.id"), ITX_EXCHANGE="rccl",
+               ITX_COMM_SELFTEST="1", ITX_TIMING="1", ITX_COMM_TIMEOUT="120")
+    pr = _run(exe, head, d, aln, out, env)
+    assert "exchange (RCCL)" in pr.stderr, pr.stderr[-1500:]
+    _same_dir(ref_dir, out)
+    # and with the communicator made at the exchange instead (the way it was before): same again
+    out2 = str(tmp_path / "self_late")
+    pr = _run(exe, head, d, aln, out2, dict(env, ITX_NO_EARLY_COMM="1", ITX_COMM_ID=str(tmp_path / "self2.id")))
+    assert "exchange (RCCL)" in pr.stderr, pr.stderr[-1500:]
+    _same_dir(ref_dir, out2)

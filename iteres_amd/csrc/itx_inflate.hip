@@ -376,11 +376,24 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
 {
     if (!out) return ITX_E_ARG;
     *out = nullptr;
+    const bool tim = getenv("ITX_TIMING_SETUP") != nullptr;
+    struct timespec tsa, tsb;
+#define SETUP_TICK(what)                                                                                                      \
+    do {                                                                                                                      \
+        if (tim) {                                                                                                            \
+            clock_gettime(CLOCK_MONOTONIC, &tsb);                                                                             \
+            fprintf(stderr, "[itx timing] inflater setup: %s %.3f s\n", what, (double)(tsb.tv_sec - tsa.tv_sec) + 1e-9 * (double)(tsb.tv_nsec - tsa.tv_nsec)); \
+            tsa = tsb;                                                                                                        \
+        }                                                                                                                     \
+    } while (0)
+    clock_gettime(CLOCK_MONOTONIC, &tsa);
     INF_HIP(hipSetDevice(device));
+    SETUP_TICK("hipSetDevice");
     itx_inflater *h = (itx_inflater *)calloc(1, sizeof *h);
     if (!h) return ITX_E_NOMEM;
     h->device = device;
     for (int k = 0; k < 2; k++) INF_HIP(hipStreamCreateWithFlags(&h->st[k], hipStreamNonBlocking));
+    SETUP_TICK("first two streams");
     for (int k = 0; k < 4; k++) INF_HIP(hipEventCreate(&h->ev[k]));
     for (int k = 0; k < 2; k++) INF_HIP(hipEventCreate(&h->ev_res_end[k]));
     for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
@@ -391,6 +404,7 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].done, hipEventDisableTiming));
         INF_HIP(hipMalloc((void **)&h->lane[k].d_next, 16));
     }
+    SETUP_TICK("lane streams, events, counters");
     INF_HIP(hipStreamCreateWithFlags(&h->st_res, hipStreamNonBlocking));
     h->n_cu = 256;
     if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
@@ -404,6 +418,8 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     hipLaunchKernelGGL(k_warm, dim3(1), dim3(1), 0, h->st[0], (uint32_t *)nullptr);
     INF_HIP(hipGetLastError());
     INF_HIP(hipStreamSynchronize(h->st[0]));
+    SETUP_TICK("first kernel (code object load)");
+#undef SETUP_TICK
     *out = h;
     return ITX_OK;
 }

@@ -9,7 +9,7 @@
  *
  * The file is a function of the arguments alone: reads are generated in segments of SEG reads, each from a generator seeded
  * by (seed, segment number), each compressed into its own run of BGZF blocks (level 1; libdeflate when the system has it,
- * zlib otherwise — MKBAM_ZLIB=1 forces zlib), by as many threads as OpenMP gives; segments are written in order. */
+ * zlib otherwise — MKBAM_ZLIB=1 forces zlib, MKBAM_LEVEL=n another level), by as many threads as OpenMP gives; segments are written in order. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <stdint.h>
@@ -62,9 +62,11 @@ static int reg2bin(int beg, int end)
 typedef struct libdeflate_compressor ld_comp;
 static ld_comp *(*ld_alloc)(int);
 static size_t (*ld_compress)(ld_comp *, const void *, size_t, void *, size_t);
-static int use_ld;
+static int use_ld, z_level = 1;                 /* MKBAM_LEVEL=1..9 (default 1; htslib writes level 6 with zlib) */
 static void ld_probe(void)
 {
+    const char *lv = getenv("MKBAM_LEVEL");
+    if (lv && atoi(lv) >= 1 && atoi(lv) <= 9) z_level = atoi(lv);
     if (getenv("MKBAM_ZLIB")) return;
     void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
     if (!h) return;
@@ -80,13 +82,13 @@ static size_t bgzf_compress(const uint8_t *src, size_t n, uint8_t *dst)
     size_t clen = 0;
     if (use_ld) {
         static __thread ld_comp *c;
-        if (!c) c = ld_alloc(1);
+        if (!c) c = ld_alloc(z_level);
         clen = c ? ld_compress(c, src, n, dst + 18, 0x10000) : 0;
     }
     if (!clen) {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
-        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        deflateInit2(&zs, z_level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
         zs.next_in = (Bytef *)src;
         zs.avail_in = (uInt)n;
         zs.next_out = dst + 18;
@@ -297,6 +299,6 @@ int main(int argc, char **argv)
         return 4;
     }
     free(seg);
-    fprintf(stderr, "wrote %lld records (%s level 1)\n", done, use_ld ? "libdeflate" : "zlib");
+    fprintf(stderr, "wrote %lld records (%s level %d)\n", done, use_ld ? "libdeflate" : "zlib", z_level);
     return 0;
 }

@@ -158,7 +158,8 @@ struct ItxDevBatch {
 // Streaming kernel (itx_stream.hip): one launch classifies n records and, per `what`, does nothing else,
 // accumulates with global atomics (stat: A/B arrays, filter: per-locus counts) or emits keys.
 enum { ITX_DO_CLASSIFY = 0, ITX_DO_ATOMIC_STAT = 1, ITX_DO_ATOMIC_LOCUS = 2, ITX_DO_EMIT = 3,
-       ITX_DO_FIND_FIRST = 4 /* plain intervals (pos, tmpend): first overlapping row in binKeeperFind's order, nothing else */ };
+       ITX_DO_FIND_FIRST = 4 /* plain intervals (pos, tmpend): first overlapping row in binKeeperFind's order, nothing else */,
+       ITX_DO_EMIT_WIDE = 5 /* EMIT with partitions of more than 2^ITX_LOGW slots: chosen by itx_launch_stream from the plan's log_w */ };
 #define ITX_STREAM_LB 5             // workgroups of the streaming kernel per CU its register budget is set for (96 VGPRs)
 // Workgroups of a streaming launch over n records: whole ROUNDS of what the chip holds at once (CUs x ITX_STREAM_LB), each
 // workgroup walking one contiguous region of about ITX_STREAM_REGION records. One round of long regions ends with the chip

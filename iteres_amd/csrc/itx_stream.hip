@@ -151,6 +151,8 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     __shared__ uint32_t s_cnt[16];
     extern __shared__ uint32_t s_pc[];                         // EMIT: keys per partition of this workgroup's region
     constexpr bool FIRST = WHAT == ITX_DO_FIND_FIRST;         // cpg lookups: first hit in list order, plain intervals
+    constexpr bool EMIT = WHAT == ITX_DO_EMIT || WHAT == ITX_DO_EMIT_WIDE;
+    constexpr bool WIDE = WHAT == ITX_DO_EMIT_WIDE;           // partitions wider than k_hist's LDS window (slot spaces beyond 33.5 M)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = threadIdx.x >> 6;
     uint4 *win = s_win[w];
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
         win[0] = make_uint4(0x3fffffffu, 0xc0000000u, 0x80000000u, 0xffffffffu);      // s, e, pbelow, rank
         win[1] = make_uint4(0, 0, 0, 0);
     }
-    if (WHAT == ITX_DO_EMIT)
+    if (EMIT)
         for (uint32_t k = threadIdx.x; k < E.n_part; k += SB) s_pc[k] = 0;
     __syncthreads();
     const size_t begin = (size_t)blockIdx.x * span;
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
                 uint32_t len, leader;
                 if (wave_run((uint32_t)hit[j], hit[j] >= 0, lane, &len, &leader)) atomicAdd(&u32[L.locus + (uint32_t)hit[j]], len);
             }
-        } else if (WHAT == ITX_DO_EMIT) {
+        } else if (EMIT) {
             // One 8-byte key per classified record: low word = type | uniq << 2 | len << 3, high word = slot.
             //   type 0: a start mark at slot and an end mark at slot + len (both inside one partition, len < 2^13: a longer
             //           range inside a wide partition goes as two keys as well)
@@ -599,7 +601,10 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
             uint32_t c = 0;
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
-                two[j] = hB[j] && ((sA[j] >> E.log_w) != (sB[j] >> E.log_w) || (E.log_w > ITX_LOGW && sB[j] - sA[j] >= (1u << ITX_LOGW)));
+                // (a coverage range of 2^13 slots or more inside one WIDE partition goes as two keys as well: the 4-byte keys of
+                // k_scatter hold 13 bits of length)
+                two[j] = WIDE ? hB[j] & ((((sA[j] ^ sB[j]) >> E.log_w) != 0u) | (sB[j] - sA[j] >= (1u << ITX_LOGW)))
+                              : hB[j] && (sA[j] >> E.log_w) != (sB[j] >> E.log_w);
                 c += (hit[j] >= 0 ? 1u : 0u) + (two[j] ? 1u : 0u);
             }
             uint32_t inc = c;                                                    // inclusive prefix sum over the lanes
@@ -670,7 +675,7 @@ __global__ __launch_bounds__(SB, ITX_LB) void k_stream(ItxDevTable T, ItxRunPara
     __syncthreads();
     if (WHAT != ITX_DO_CLASSIFY && !FIRST && threadIdx.x < 16 && s_cnt[threadIdx.x])
         atomicAdd((unsigned long long *)&u64[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    if (WHAT == ITX_DO_EMIT) {
+    if (EMIT) {
         if (lane == 0) blk_cnt[4 * blockIdx.x + w] = w_keys;
         // reserve this region's places: ONE add per touched partition, on one of 8 sub-cursors (workgroup id mod 8 —
         // workgroups are dealt round-robin over the 8 XCDs, so no address sees more than n_blocks/8 adds). The
@@ -751,8 +756,12 @@ int itx_launch_stream(int what, const ItxDevTable &T, const ItxRunParams &P, con
         hipLaunchKernelGGL(k_stream<ITX_DO_FIND_FIRST>, g, b, 0, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0, blk_cnt, E);
         break;
     case ITX_DO_EMIT:
-        hipLaunchKernelGGL(k_stream<ITX_DO_EMIT>, g, b, (size_t)E.n_part * 4, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0,
-                           blk_cnt, E);
+        if (E.log_w > ITX_LOGW)
+            hipLaunchKernelGGL(k_stream<ITX_DO_EMIT_WIDE>, g, b, (size_t)E.n_part * 4, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0,
+                               blk_cnt, E);
+        else
+            hipLaunchKernelGGL(k_stream<ITX_DO_EMIT>, g, b, (size_t)E.n_part * 4, st, T, P, B, n, span, d_hit_row, u64, u32, L, keys0,
+                               blk_cnt, E);
         break;
     default:
         itx_set_error("internal: unknown stream action %d", what);

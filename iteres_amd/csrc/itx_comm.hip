@@ -96,6 +96,13 @@ static int write_whole(const std::string &path, const void *a, size_t na, const 
     return ITX_OK;
 }
 
+// rank 0 could not get as far as a communicator id: the ranks waiting for the id file find this instead and fall back with it
+// (to the exchange through files) at once, not after their timeout
+static void tell_no_id(const itx_comm *c)
+{
+    if (c->rank == 0 && c->world > 1 && !c->id_path.empty()) (void)write_whole(c->id_path, "NOID", 4, nullptr, 0, nullptr, 0);
+}
+
 extern "C" int itx_comm_create(int rank, int world, int device, const char *id_path, int mode, itx_comm **out)
 {
     if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && (!id_path || !*id_path)) || (mode != ITX_COMM_RCCL && mode != ITX_COMM_FILE)) {
@@ -120,10 +127,14 @@ extern "C" int itx_comm_create(int rank, int world, int device, const char *id_p
         *out = c;
         return ITX_OK;
     }
-    c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!getenv("ITX_COMM_NO_RCCL")) {                     // (tests: a rank that cannot load the library)
+        c->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!c->lib) c->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    }
     if (!c->lib) {
-        itx_set_error("cannot load librccl.so.1: %s", dlerror());
+        const char *why = dlerror();
+        itx_set_error("cannot load librccl.so.1: %s", why ? why : "switched off (ITX_COMM_NO_RCCL)");
+        tell_no_id(c);
         delete c;
         return ITX_E_NO_DEVICE;
     }
@@ -134,12 +145,14 @@ extern "C" int itx_comm_create(int rank, int world, int device, const char *id_p
     c->p_errstr = (decltype(c->p_errstr))dlsym(c->lib, "ncclGetErrorString");
     if (!c->p_get_id || !c->p_init_rank || !c->p_reduce || !c->p_destroy) {
         itx_set_error("librccl lacks an entry point this path needs");
+        tell_no_id(c);
         delete c;
         return ITX_E_NO_DEVICE;
     }
     hipError_t he = hipSetDevice(device);
     if (he != hipSuccess) {
         itx_set_error("hipSetDevice(%d) failed: %s", device, hipGetErrorString(he));
+        tell_no_id(c);
         delete c;
         return ITX_E_NO_DEVICE;
     }
@@ -149,6 +162,7 @@ extern "C" int itx_comm_create(int rank, int world, int device, const char *id_p
         ncclResult_t r = c->p_get_id(&id);
         if (r != ncclSuccess) {
             itx_set_error("ncclGetUniqueId failed: %s", c->p_errstr ? c->p_errstr(r) : "?");
+            tell_no_id(c);
             delete c;
             return ITX_E_NO_DEVICE;
         }
@@ -164,10 +178,12 @@ extern "C" int itx_comm_create(int rank, int world, int device, const char *id_p
             return rc;
         }
         FILE *f = fopen(c->id_path.c_str(), "rb");
-        const bool ok = f && fread(&id, 1, sizeof id, f) == sizeof id;
+        const size_t got = f ? fread(&id, 1, sizeof id, f) : 0;
+        const bool ok = got == sizeof id;
         if (f) fclose(f);
         if (!ok) {
-            itx_set_error("cannot read the communicator id from %s", c->id_path.c_str());
+            if (got == 4 && memcmp(&id, "NOID", 4) == 0) itx_set_error("rank 0 could not make a communicator id");
+            else itx_set_error("cannot read the communicator id from %s", c->id_path.c_str());
             delete c;
             return ITX_E_STATE;
         }

@@ -8,6 +8,7 @@ import filecmp
 import os
 import struct
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -214,3 +215,29 @@ def test_command_walks_the_rccl_exchange_with_one_rank(head, exe, big_case, tmp_
     pr = _run(exe, head, d, aln, out2, dict(env, ITX_NO_EARLY_COMM="1", ITX_COMM_ID=str(tmp_path / "self2.id")))
     assert "exchange (RCCL)" in pr.stderr, pr.stderr[-1500:]
     _same_dir(ref_dir, out2)
+
+
+def test_rank0_without_rccl_sends_the_others_to_the_files(exe, big_case, tmp_path):
+    """Two ranks started by hand (the way bench.py starts them), RCCL asked for. Rank 0 cannot load the library
+    (ITX_COMM_NO_RCCL): instead of the communicator id the waiting rank finds a note, gives RCCL up at once (not after its
+    timeout) and both hand their partials over through files. Same files as one rank."""
+    d = big_case
+    aln = str(d / "a.bam")
+    ref_dir = str(tmp_path / "plain")
+    _run(exe, ["stat", "-w"], d, aln, ref_dir, dict(os.environ))
+    args = [exe, "stat", "-w", "-o", "out", str(d / "chrom.sizes"), str(d / "rep.sizes"), str(d / "rmsk.txt"), aln]
+    procs = []
+    t0 = time.time()
+    for r in range(2):
+        out = tmp_path / f"rank{r}"
+        out.mkdir()
+        env = dict(os.environ, ITX_RANK=str(r), ITX_WORLD="2", ITX_DEVICE="0", ITX_COMM_ID=str(tmp_path / "job.id"), ITX_EXCHANGE="rccl",
+                   ITX_SPLIT_MIN="1", ITX_TIMING="1", ITX_COMM_TIMEOUT="100")
+        if r == 0:
+            env["ITX_COMM_NO_RCCL"] = "1"
+        procs.append(subprocess.Popen(args, cwd=out, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    errs = [p.communicate(timeout=300)[1] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], errs
+    assert time.time() - t0 < 60                                    # nobody sat out a timeout
+    assert "exchange (files)" in errs[0] and "could not make a communicator id" in errs[1], errs
+    _same_dir(ref_dir, str(tmp_path / "rank0"))

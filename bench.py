@@ -374,7 +374,7 @@ def main():
         e = dict(env)
         if world > 1:
             e.update(ITX_RANK=str(rank), ITX_WORLD=str(world), ITX_DEVICE=str(local_rank), ITX_COMM_ID=os.path.join(wd, f"comm_{nonce[0]}_{tag}_{step}.id"),
-                     ITX_EXCHANGE="file" if share_gpu else "rccl")
+                     ITX_EXCHANGE="file" if share_gpu else "rccl", ITX_COMM_TIMEOUT=os.environ.get("ITX_COMM_TIMEOUT", "300"))
         wall, rc, err, seen = run_timed(OURS, base_args(wd) + [aln], scratch, e, (SCAN_BEGIN, SCAN_END))
         if rc != 0:
             raise RuntimeError(f"rank {rank}: iteres stat failed ({rc}): {err[-800:]}")

@@ -124,6 +124,26 @@ ITXI_FN void itxi_batch(ItxiIn &in, uint32_t i)
     if (i < in.stop) ITXI_LOAD4(in.w, i, in.b0, in.b1, in.b2, in.b3);
 }
 
+#ifdef ITXI_SIMPLE_IN
+// One word of look-ahead instead of the FIFO: the word at ip sits in a0, its successor is asked for when a0 is taken. Fewer
+// registers to carry through the symbol loop (the FIFO's eight words are shuffled on every take), one 4-byte load per refill.
+ITXI_FN uint32_t itxi_take(ItxiIn &in)
+{
+    const uint32_t w = in.a0;
+    in.ip++;
+    in.a0 = in.ip < in.stop ? ITXI_LOADW(in.w, in.ip) : 0u;
+    return w;
+}
+ITXI_FN void itxi_in_start(ItxiIn &in, uint32_t byte_pos)
+{
+    in.stop = (in.end + 3u) >> 2;                                  // words that hold bytes of the block; what lies behind reads as zeros
+    in.ip = byte_pos >> 2;
+    in.a0 = in.ip < in.stop ? ITXI_LOADW(in.w, in.ip) : 0u;
+    const uint32_t skip = (byte_pos & 3u) * 8u;
+    in.bb = (uint64_t)(itxi_take(in) >> skip);
+    in.bn = 32u - skip;
+}
+#else
 ITXI_FN uint32_t itxi_take(ItxiIn &in)                      // the word at ip; keeps the read-ahead going
 {
     const uint32_t w = in.a0;
@@ -160,6 +180,7 @@ ITXI_FN void itxi_in_start(ItxiIn &in, uint32_t byte_pos)
     in.bb = (uint64_t)(itxi_take(in) >> skip);
     in.bn = 32u - skip;
 }
+#endif
 
 // at least 33 valid bits afterwards
 ITXI_FN void itxi_refill(ItxiIn &in)

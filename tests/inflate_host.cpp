@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <vector>
 #define ITXI_WAVE 1u
+#define ITXI_SIMPLE_IN
 #define ITXI_FN static inline
 #define ITXI_UNI(x) (x)
 #define ITXI_BCAST(v, j) (v)

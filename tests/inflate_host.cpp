@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include <vector>
 #define ITXI_WAVE 1u
-#define ITXI_SIMPLE_IN
+// the input form is the build's choice: -DITXI_SIMPLE_IN (what the device build uses) or the 16-byte FIFO
 #define ITXI_FN static inline
 #define ITXI_UNI(x) (x)
 #define ITXI_BCAST(v, j) (v)

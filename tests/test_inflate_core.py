@@ -14,10 +14,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib(tmp_path_factory):
+# both input forms of pass 1: one word of look-ahead (the device build's, -DITXI_SIMPLE_IN) and the 16-byte read-ahead FIFO
+INPUT_FORMS = [["-DITXI_SIMPLE_IN"], []]
+
+
+@pytest.fixture(scope="module", params=INPUT_FORMS, ids=["word_ahead", "fifo"])
+def lib(request, tmp_path_factory):
     so = str(tmp_path_factory.mktemp("inflate") / "libinflate_host.so")
-    subprocess.check_call(["g++", "-O2", "-g", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", so, os.path.join(ROOT, "tests", "inflate_host.cpp")])
+    subprocess.check_call(["g++", "-O2", "-g", "-shared", "-fPIC", "-Wno-unknown-pragmas"] + request.param + ["-o", so, os.path.join(ROOT, "tests", "inflate_host.cpp")])
     L = C.CDLL(so)
     L.itx_inflate_host.restype = C.c_int
     L.itx_inflate_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -129,13 +133,14 @@ def _fnv(b):
     return h
 
 
-def test_address_sanitizer_exact_buffers(tmp_path):
+@pytest.mark.parametrize("form", INPUT_FORMS, ids=["word_ahead", "fifo"])
+def test_address_sanitizer_exact_buffers(form, tmp_path):
     """The same decoder under -fsanitize=address,undefined with EXACT-size buffers (input: the block + its 8-byte trailer + the
     16 bytes of padding the C ABI asks for; output: usize bytes). Covers what a fuzz without a sanitizer cannot see: reads
     beyond the padding. The crafted case is the one that used to run away: a dynamic block whose 1-bit code maps the zero
     bytes behind a truncated block to literals, usize = 65536 — it must stop with an error inside the padding."""
     exe = str(tmp_path / "inflate_asan")
-    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wno-unknown-pragmas", "-o", exe,
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wno-unknown-pragmas"] + form + ["-o", exe,
                            os.path.join(ROOT, "tests", "inflate_asan_main.cpp"), os.path.join(ROOT, "tests", "inflate_host.cpp")])
     rng = np.random.default_rng(11)
     cases, expect = [], []

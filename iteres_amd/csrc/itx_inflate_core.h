@@ -127,18 +127,27 @@ ITXI_FN void itxi_batch(ItxiIn &in, uint32_t i)
 #ifdef ITXI_SIMPLE_IN
 // One word of look-ahead instead of the FIFO: the word at ip sits in a0, its successor is asked for when a0 is taken. Fewer
 // registers to carry through the symbol loop (the FIFO's eight words are shuffled on every take), one 4-byte load per refill.
+// The load is unconditional (its index clamped to the block's last word) and its value is masked only when it is TAKEN: a
+// load under a condition is waited for where it is issued (the compiler merges it with the zero of the other branch), and
+// the look-ahead would hide nothing.
+ITXI_FN void itxi_ahead(ItxiIn &in)
+{
+    const bool inside = in.ip < in.stop;
+    in.a0 = ITXI_LOADW(in.w, inside ? in.ip : in.stop - 1u);
+    in.a1 = inside ? 0xffffffffu : 0u;
+}
 ITXI_FN uint32_t itxi_take(ItxiIn &in)
 {
-    const uint32_t w = in.a0;
+    const uint32_t w = in.a0 & in.a1;
     in.ip++;
-    in.a0 = in.ip < in.stop ? ITXI_LOADW(in.w, in.ip) : 0u;
+    itxi_ahead(in);
     return w;
 }
 ITXI_FN void itxi_in_start(ItxiIn &in, uint32_t byte_pos)
 {
-    in.stop = (in.end + 3u) >> 2;                                  // words that hold bytes of the block; what lies behind reads as zeros
+    in.stop = (in.end + 3u) >> 2;                                  // words that hold bytes of the block (>= 1); what lies behind reads as zeros
     in.ip = byte_pos >> 2;
-    in.a0 = in.ip < in.stop ? ITXI_LOADW(in.w, in.ip) : 0u;
+    itxi_ahead(in);
     const uint32_t skip = (byte_pos & 3u) * 8u;
     in.bb = (uint64_t)(itxi_take(in) >> skip);
     in.bn = 32u - skip;

@@ -270,10 +270,14 @@ def test_two_engines_partials_vs_oracle(filter_mode):
     tab.close()
 
 
-def test_hot_partition_split_items_vs_oracle():
-    """k_hist's split-item branch (a partition with more than 65 535 keys is cut into several items, which then add their
+@pytest.mark.parametrize("log_w", [None, 15])
+def test_hot_partition_split_items_vs_oracle(log_w, monkeypatch):
+    """(log_w 15: the same through the wide-partition kernels — several LDS windows per partition, the slot space ending
+    inside the first.) k_hist's split-item branch (a partition with more than 65 535 keys is cut into several items, which then add their
     differences with atomics instead of owning the partition): one short consensus, 300 k reads that all choose rows of it —
     every key of the batch lands in ONE partition — compared with the oracle directly, both accumulate paths."""
+    if log_w:
+        monkeypatch.setenv("ITX_PART_LOGW", str(log_w))
     chroms = [("c1", 30_000_000)]
     rng = np.random.default_rng(5)
     n_rows = 20_000

@@ -59,6 +59,12 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=500_000_000, help="reads in the BAM (configs[2]: 500 M)")
     ap.add_argument("--seq-len", type=int, default=100, help="bases + qualities per record in the BAM (0: none)")
+    ap.add_argument("--content", default="hiseq", choices=("legacy", "hiseq", "novaseq"),
+                    help="what the BAM's SEQ/QUAL/names look like (tools/mkbam.c): hiseq = independent bases + 40-value qualities (literal-heavy, the default), "
+                         "novaseq = 4-bin qualities, legacy = round 2's file (97 %% of the bytes out of LZ77 matches)")
+    ap.add_argument("--cigar", default="mixed", choices=("simple", "mixed"), help="mixed: 5 %% of the CIGARs carry S / D / I / N (SURVEY.md 8(d))")
+    ap.add_argument("--paired", type=int, default=0, help="1: fragments of two reads, isize ~ N(350, 60) (SURVEY.md 8(d)'s paired variant)")
+    ap.add_argument("--pileup", type=int, default=0, help="K loci of the genome at ~2000x depth")
     ap.add_argument("--rows", type=int, default=5_500_000)
     ap.add_argument("--cpu-reads", type=int, default=15_000_000, help="reads of the sample the reference binary is timed on (0 = skip)")
     ap.add_argument("--replay-steps", type=int, default=10, help="launches of the resident hot path behind `roofline` (0 = skip)")
@@ -114,7 +120,8 @@ def vram_settle(device, gb=176.0, pause=6.0):
 def ensure_inputs(a, threads):
     """chrom.sizes / rep.sizes / rmsk.txt / reads.bam / sample.bam for these parameters, generated once per box."""
     from iteres_amd import synth
-    key = f"r{a.reads}_s{a.seq_len}_t{a.rows}_c{a.cpu_reads}"
+    mkopts = mkbam_options(a)
+    key = f"r{a.reads}_s{a.seq_len}_t{a.rows}_c{a.cpu_reads}_" + "_".join(o.split("=")[1] for o in mkopts)
     wd = a.workdir or os.path.join("/tmp", f"itx_bench_{key}")
     os.makedirs(wd, exist_ok=True)
     done = os.path.join(wd, "inputs.json")
@@ -130,13 +137,22 @@ def ensure_inputs(a, threads):
     synth.write_rmsk(os.path.join(wd, "rmsk.txt"), tb, workers=threads)
     t1 = time.time()
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
-    subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.reads), os.path.join(wd, "reads.bam"), str(a.seq_len), "7"], env=env)
+    subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.reads), os.path.join(wd, "reads.bam"), str(a.seq_len), "7"] + mkopts, env=env)
     if a.cpu_reads > 0:
-        subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.cpu_reads), os.path.join(wd, "sample.bam"), str(a.seq_len), "7"], env=env)
+        subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.cpu_reads), os.path.join(wd, "sample.bam"), str(a.seq_len), "7"] + mkopts, env=env)
     info = {"table_s": round(t1 - t0, 1), "bam_s": round(time.time() - t1, 1), "bam_bytes": os.path.getsize(os.path.join(wd, "reads.bam")),
             "n_rep": len(tb.names), "n_fam": len(tb.fams), "n_cla": len(tb.clas)}
     json.dump(info, open(done, "w"))
     return wd, info
+
+
+def mkbam_options(a):
+    o = [f"content={getattr(a, 'content', 'legacy')}", f"cigar={getattr(a, 'cigar', 'simple')}"]
+    if getattr(a, "paired", 0):
+        o.append("paired=1")
+    if getattr(a, "pileup", 0):
+        o.append(f"pileup={a.pileup}")
+    return o
 
 
 def base_args(wd):

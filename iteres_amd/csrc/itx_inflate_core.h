@@ -38,6 +38,13 @@
 #error "define the ITXI_* hooks before including this file"
 #endif
 
+// timing-only experiment builds (tools/build_variant.sh): -DITXI_EXP_NOSTORE leaves pass 1's token and literal stores out
+#ifdef ITXI_EXP_NOSTORE
+#define ITXI_EXP_STORE(...) ((void)0)
+#else
+#define ITXI_EXP_STORE(...) __VA_ARGS__
+#endif
+
 #ifndef ITXI_RING
 #define ITXI_RING 4096u                    // pass 2: bytes of output kept in LDS; a power of two, a multiple of the stripe. 6 KB of LDS per
                                            // wave with the literal stage: 26 waves per CU instead of 13 with 8 + 4 KB — pass 2 is a chain of LDS
@@ -331,7 +338,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
         lacc |= (uint32_t)(byte) << ((n_lit & 3u) * 8u);     \
         n_lit++;                                             \
         if ((n_lit & 3u) == 0) {                             \
-            lit32[(n_lit >> 2) - 1u] = lacc;                 \
+            ITXI_EXP_STORE(lit32[(n_lit >> 2) - 1u] = lacc); \
             lacc = 0;                                        \
         }                                                    \
     } while (0)
@@ -460,7 +467,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (dist > produced) return ITXI_E_DIST;
                 if (len > usize - produced) return ITXI_E_OUTPUT;
                 ItxiPair *tp = reinterpret_cast<ItxiPair *>(K.tok) + n_tok;
-                *tp = ItxiPair{run | (len << 16), dist};
+                ITXI_EXP_STORE(*tp = ItxiPair{run | (len << 16), dist});
                 n_tok++;
                 run = 0;
                 produced += len;

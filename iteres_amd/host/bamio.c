@@ -285,12 +285,42 @@ static void hz_free(hz_t *z)
 
 static inline size_t looks_like_record(const uint8_t *u, size_t p, size_t L, int n_targets);
 
+/* looks_like_record for a chain that may run out of inflated bytes: *step = the record's bytes when it is well-formed
+ * and complete; returns 1 then, 0 when what is there rules a record out, -1 when only more data can tell (the fixed part
+ * or the record's end lies beyond u[0, L)) */
+static int32_t rd_i32(const uint8_t *p);
+static uint32_t rd_u32(const uint8_t *p);
+static int record_or_short(const uint8_t *u, size_t p, size_t L, int n_targets, size_t *step)
+{
+    if (p + 36 > L) return -1;
+    const int32_t bl = rd_i32(u + p);
+    if (bl < 32) return 0;
+    const uint8_t *core = u + p + 4;
+    const int32_t tid = rd_i32(core), pos = rd_i32(core + 4), l_qseq = rd_i32(core + 16), mtid = rd_i32(core + 20), mpos = rd_i32(core + 24);
+    const uint32_t x1 = rd_u32(core + 8), x2 = rd_u32(core + 12);
+    const size_t l_qname = x1 & 0xff, n_cigar = x2 & 0xffff;
+    if (tid < -1 || tid >= n_targets || mtid < -1 || mtid >= n_targets || pos < -1 || mpos < -1 || l_qseq < 0 || l_qname == 0) return 0;
+    const size_t need = l_qname + 4 * n_cigar + ((size_t)l_qseq + 1) / 2 + (size_t)l_qseq;
+    if (need > (size_t)bl - 32) return 0;
+    if (p + 36 + l_qname > L) return -1;
+    if (u[p + 36 + l_qname - 1] != 0) return 0;
+    if (p + 4 + (size_t)bl > L) return -1;
+    *step = 4 + (size_t)bl;
+    return 1;
+}
+
 /* Where a share of the file may begin: a point at or after compressed byte `at` where a BAM record starts, as (file offset
  * of a BGZF block, inflated bytes into that block — fewer than the block holds, size of that block). Two ranks that
  * call this with the same arguments get the same point, which is all that the split needs: any true record start will do.
  * It is a GUESS (a block header whose BSIZE chain leads to more headers; 8 well-formed records in a row): the rank whose
  * share ENDS there verifies it — its own chain of records, which starts at a known record start, has to arrive exactly
- * there — and the job falls back to one rank when a boundary does not hold. Returns 0 when no such point is found. */
+ * there — and the job falls back to one rank when a boundary does not hold.
+ * Returns 1 with the point; 0 when the file ends without one (nothing starts behind `at`: the share before runs to the
+ * end); -1 when the search had to be given up (no block header within reach, damaged blocks, or the chain of a candidate
+ * still undecided after GIVE_UP inflated bytes — records of megabytes): the caller must not trust ANY share then. A chain
+ * that runs out of inflated bytes is never a reason to reject a candidate: more blocks are inflated until it is decided
+ * (with a fixed margin instead, true starts were rejected once eight records no longer fit into it — long reads — and a
+ * boundary that fails on one side while a later one holds made two ranks count the same records). */
 static int find_split(int fd, size_t fsize, size_t at, int n_targets, size_t *pB, size_t *pc, size_t *pcsize)
 {
     if (at >= fsize) return 0;
@@ -327,33 +357,51 @@ static int find_split(int fd, size_t fsize, size_t at, int n_targets, size_t *pB
         }
     }
     free(buf);
-    if (B == SIZE_MAX) return 0;
-    enum { K = 8, MARGIN = 256u << 10, GIVE_UP = 64u << 20 };
+    if (B == SIZE_MAX) return at + have >= fsize && have <= (1u << 16) ? 0 : -1;     /* the last bytes of a file hold no block start: fine; no header in 64 KiB: not a BGZF file here */
+    enum { K = 8, GIVE_UP = 64u << 20 };
     hz_t z;
     memset(&z, 0, sizeof z);
     z.fd = fd;
     z.off = B;
     z.size = fsize;
     size_t c = 0, found = SIZE_MAX;
-    for (;;) {
-        int st = 0;
-        for (int i = 0; i < 4 && st == 0; i++) st = hz_block(&z);
-        const int at_end = st != 0;
-        const size_t limit = at_end ? z.len : (z.len > MARGIN ? z.len - MARGIN : 0);
-        for (; c < limit && found == SIZE_MAX; c++) {
+    int at_end = 0, gave_up = 0;
+    while (found == SIZE_MAX) {
+        if (!at_end) {
+            int st = 0;
+            for (int i = 0; i < 4 && st == 0; i++) st = hz_block(&z);
+            if (st < 0) {                                            /* a damaged block: nothing behind it can be vouched for */
+                gave_up = 1;
+                break;
+            }
+            at_end = st != 0;
+        }
+        int undecided = 0;
+        for (; c < z.len && found == SIZE_MAX; c++) {
             size_t a = c;
-            int k = 0;
+            int k = 0, why = 1;
             while (k < K) {
-                const size_t step = looks_like_record(z.u, a, z.len, n_targets);
-                if (!step) break;
+                size_t step = 0;
+                why = record_or_short(z.u, a, z.len, n_targets, &step);
+                if (why != 1) break;
                 a += step;
                 k++;
             }
-            if (k == K || (k > 0 && at_end && a == z.len)) found = c;
+            if (k == K || (k > 0 && at_end && a == z.len)) {
+                found = c;
+            } else if (why < 0 && !at_end) {
+                undecided = 1;                                       /* this candidate needs more bytes: come back to it */
+                break;
+            }
         }
-        if (found != SIZE_MAX || at_end || z.len > GIVE_UP) break;
+        if (found != SIZE_MAX) break;
+        if (at_end) break;                                           /* every byte looked at: no record starts here */
+        if (undecided && z.len > GIVE_UP) {
+            gave_up = 1;
+            break;
+        }
     }
-    int ok = 0;
+    int ok = gave_up ? -1 : 0;
     if (found != SIZE_MAX) {
         /* as (block, offset inside it): the block that holds that byte */
         for (size_t i = 0; i < z.nb; i++)
@@ -1129,14 +1177,21 @@ aln_reader *aln_open_range(const char *path, size_t lo, size_t hi)
     }
     int empty = 0;
     size_t B = 0, c = 0, cs = 0;
-    if (hi != SIZE_MAX && hi < fsize && find_split(fileno(f), fsize, hi, r->n_targets, &B, &c, &cs)) {
-        r->rg_end_block = B;
-        r->rg_end_off = c;
-        r->rg_end_csize = cs;
+    if (hi != SIZE_MAX && hi < fsize) {
+        const int fs = find_split(fileno(f), fsize, hi, r->n_targets, &B, &c, &cs);
+        if (fs > 0) {
+            r->rg_end_block = B;
+            r->rg_end_off = c;
+            r->rg_end_csize = cs;
+        } else if (fs < 0) {
+            r->rg_suspect = 1;                                     /* the search was given up: no share of this job can be trusted (whole-job fallback) */
+        }
     }
     if (lo > 0) {
-        if (!find_split(fileno(f), fsize, lo, r->n_targets, &B, &c, &cs)) {
-            empty = 1;                                             /* no record starts behind lo: the share before this one runs to the end */
+        const int fs = find_split(fileno(f), fsize, lo, r->n_targets, &B, &c, &cs);
+        if (fs <= 0) {
+            empty = 1;                                             /* 0: no record starts behind lo, the share before this one runs to the end */
+            if (fs < 0) r->rg_suspect = 1;                         /* given up: see above */
         } else {
             if (r->rg_end_block != SIZE_MAX && (B > r->rg_end_block || (B == r->rg_end_block && c >= r->rg_end_off))) empty = 1;
             r->rg_lo_block = B;
@@ -1188,7 +1243,7 @@ int aln_find_split(const char *path, size_t at, size_t *block, size_t *off, size
     r->hz = NULL;
     hz_free(&z);
     int found = -1;
-    if (rc == 0) found = find_split(fileno(f), (size_t)sb.st_size, at, r->n_targets, block, off, csize);
+    if (rc == 0) found = find_split(fileno(f), (size_t)sb.st_size, at, r->n_targets, block, off, csize);     /* 1 found, 0 none up to the end, -1 given up */
     aln_close(r);
     return found;
 }

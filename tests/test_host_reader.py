@@ -212,3 +212,50 @@ def test_split_points_can_be_fooled_by_decoys(split_dump, tmp_path):
     res = _splits(split_dump, path, [len(comp) * k // 4 for k in (1, 2, 3)])
     assert all(f == 1 for _, f, _, _, _ in res)
     assert any(uoff[b] + o not in starts for _, _, b, o, _ in res)
+
+
+def test_split_points_with_long_records_of_mixed_lengths(split_dump, tmp_path):
+    """Records of 60 - 120 KB between short ones (long reads): eight of them in a row are 0.5 - 1 MB of inflated bytes, more
+    than any fixed margin of look-ahead. Every boundary of an 8-way split must still be decided — found (and a true record
+    start) or "nothing starts behind it" — never given up on one side of a boundary while a later one holds: that made two
+    ranks count the same records. The shares' union is then the file: a share ends where the next begins (same call, same
+    answer), and once a boundary finds nothing no later one finds anything."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(77)
+    raw = bytearray(b"BAM\1" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 3) + b"c1\0" + struct.pack("<i", 200_000_000))
+    pos = 0
+    for i in range(1100):
+        # the first 80 MB of the file hold long records only (no eight in a row fit a small margin for longer than any
+        # give-up distance), the rest is mixed
+        l_seq = int(rng.integers(60_000, 120_000)) if (i < 600 or rng.random() < 0.45) else int(rng.integers(50, 200))
+        name = f"read{i}".encode() + b"\0"
+        body = struct.pack("<iiIIiiii", 0, pos, (4681 << 16) | (30 << 8) | len(name), (0 << 16) | 1, l_seq, -1, -1, 0) + name + struct.pack("<I", l_seq << 4)
+        body += bytes(rng.integers(0, 256, (l_seq + 1) // 2, dtype=np.uint8)) + bytes([30]) * l_seq
+        raw += struct.pack("<i", len(body)) + body
+        pos += int(rng.integers(1, 400))
+    comp = bytearray()
+    for off in range(0, len(raw), 0xff00):
+        piece = bytes(raw[off:off + 0xff00])
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        d = co.compress(piece) + co.flush()
+        comp += bytes.fromhex("1f8b08040000000000ff0600424302 00".replace(" ", "")) + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(piece), len(piece))
+    comp += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    path = str(tmp_path / "long.bam")
+    open(path, "wb").write(comp)
+    _, blocks, starts = _record_starts(path)
+    uoff = {int(b["coff"]): (int(b["uoff"]), int(b["usize"])) for b in blocks}
+    n = 8
+    res = _splits(split_dump, path, [len(comp) * k // n for k in range(1, n)] + [len(comp) - 40, len(comp) - 200_000])
+    none_seen = False
+    prev = -1
+    for at, f, b, o, cs in sorted(res):
+        assert f in (0, 1), f"boundary at {at} was given up"
+        if f == 0:
+            none_seen = True
+            continue
+        assert not none_seen, "a boundary behind one that found nothing found something"
+        assert b in uoff and b >= at and o < uoff[b][1] and uoff[b][0] + o in starts, (at, b, o)
+        assert uoff[b][0] + o >= prev
+        prev = uoff[b][0] + o
+    assert sum(f for _, f, _, _, _ in res) >= n - 2

@@ -21,6 +21,10 @@ def main():
     a = A()
     a.reads, a.seq_len, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     a.rows, a.cpu_reads, a.workdir = 5_500_000, 0, ""
+    # ITX_AB_MKBAM="content=hiseq cigar=mixed paired=1 pileup=20": what the BAM looks like (default: round 2's legacy content)
+    for kv in os.environ.get("ITX_AB_MKBAM", "").split():
+        k, v = kv.split("=", 1)
+        setattr(a, k, int(v) if v.isdigit() else v)
     wd, info = bench.ensure_inputs(a, 16)
     settings = [("base", {})]
     for spec in sys.argv[4:]:

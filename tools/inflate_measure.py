@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Scratch measurement: itx_inflate_bgzf on a synthetic BAM (tools/mkbam.c), whole call and kernel-only, next to zlib
-on one host core.   python tools/inflate_measure.py [n_reads=2000000] [seq_len=100] [repeat=3]"""
+on one host core.   python tools/inflate_measure.py [n_reads=2000000] [seq_len=100] [repeat=3] [mkbam key=value options ...]
+ITX_MEASURE_NOCHECK=1 skips the comparison with zlib (experiment builds whose pass 1 stores nothing)."""
 import ctypes as C
 import os
 import subprocess
@@ -20,15 +21,16 @@ def main():
     n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
     seq_len = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    mkopts = sys.argv[4:]
     mk = os.path.join(ROOT, "tools", "mkbam")
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", mk, os.path.join(ROOT, "tools", "mkbam.c"), "-lz", "-ldl"])
     tmp = tempfile.mkdtemp(prefix="itx_inf_")
     synth.write_sizes(os.path.join(tmp, "chrom.sizes"), synth.HG38_CHROMS)
-    subprocess.check_call([mk, os.path.join(tmp, "chrom.sizes"), str(n_reads), os.path.join(tmp, "reads.bam"), str(seq_len), "7"])
+    subprocess.check_call([mk, os.path.join(tmp, "chrom.sizes"), str(n_reads), os.path.join(tmp, "reads.bam"), str(seq_len), "7"] + mkopts)
     comp = open(os.path.join(tmp, "reads.bam"), "rb").read()
     blocks = eng.index_bgzf(comp)
     total = int(blocks["usize"].astype(np.uint64).sum())
-    print(f"{len(comp) / 1e6:.1f} MB compressed, {total / 1e6:.1f} MB inflated, {len(blocks)} blocks", flush=True)
+    print(f"mkbam options {mkopts}: {len(comp) / 1e6:.1f} MB compressed, {total / 1e6:.1f} MB inflated, {len(blocks)} blocks", flush=True)
     L = eng.load()
     h = eng.Inflater()
     cp = L.itx_pinned_alloc(len(comp) + 64)
@@ -50,6 +52,8 @@ def main():
         L.itx_inflater_last_ms(h._h, C.byref(a), C.byref(b))
         L.itx_inflater_last_resolve_all_ms(h._h, C.byref(c))
     print(f"kernels only, {len(blocks)} blocks / {total / 1e6:.0f} MB per launch: pass 1 {a.value:.2f} ms = {total / a.value / 1e6:.1f} GB/s, pass 2 (all groups) {c.value:.2f} ms = {total / c.value / 1e6:.1f} GB/s of inflated bytes", flush=True)
+    if os.environ.get("ITX_MEASURE_NOCHECK"):
+        return
     out = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(total,))
     # every block against zlib (threads: zlib releases the GIL)
     from concurrent.futures import ThreadPoolExecutor

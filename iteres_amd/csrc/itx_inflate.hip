@@ -310,6 +310,31 @@ __global__ __launch_bounds__(256) void k_parse(const uint8_t *__restrict__ u, co
     if ((threadIdx.x & 63u) == 0 && (bp | bx)) atomicOr(flags, (bp ? 1u : 0u) | (bx ? 2u : 0u));
 }
 
+// bytes [src, src + n) of a buffer moved UP by `shift` bytes (0 < shift; the ranges overlap): ONE workgroup walks the range from
+// its end in chunks; a chunk is loaded whole, then — behind a barrier — stored: its destination lies above every source byte that is
+// still to be read. For shifts too small to move the bytes in a few device-to-device copies (itx_bamwin_carry).
+#define MOVE_THREADS 1024u
+#define MOVE_PER_THREAD 64u                  /* bytes per thread and chunk */
+__global__ __launch_bounds__(MOVE_THREADS) void k_move_up(uint8_t *__restrict__ buf, size_t src, size_t n, size_t shift)
+{
+    const size_t chunk = (size_t)MOVE_THREADS * MOVE_PER_THREAD;
+    for (size_t left = n; left > 0;) {
+        const size_t m = left < chunk ? left : chunk, c0 = src + left - m;
+        uint8_t v[MOVE_PER_THREAD];
+        const size_t a = (size_t)threadIdx.x * MOVE_PER_THREAD;
+        uint32_t k_n = 0;
+        if (a < m) k_n = (uint32_t)(m - a < MOVE_PER_THREAD ? m - a : MOVE_PER_THREAD);
+#pragma unroll
+        for (uint32_t k = 0; k < MOVE_PER_THREAD; k++) v[k] = k < k_n ? buf[c0 + a + k] : (uint8_t)0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < MOVE_PER_THREAD; k++)
+            if (k < k_n) buf[c0 + a + k + shift] = v[k];
+        __syncthreads();
+        left -= m;
+    }
+}
+
 // launched once when an inflater is made: loading the library's code objects costs a tenth of a second, and the helper
 // thread that creates the inflater has it to spare
 __global__ void k_warm(uint32_t *p)
@@ -863,13 +888,20 @@ extern "C" int itx_bamwin_carry(itx_inflater *h, int from, int to)
                           tail, h->win[to].cap);
             return ITX_E_LIMIT;
         }
-        // move [WIN_HEAD, WIN_HEAD + fresh) to [tail, tail + fresh): from the end, in pieces no longer than the shift (no piece overlaps its source)
+        // move [WIN_HEAD, WIN_HEAD + fresh) to [tail, tail + fresh): from the end, in pieces no longer than the shift (no piece
+        // overlaps its source) — when the shift is a megabyte or more; a tail only just over the head room would mean millions of
+        // tiny copies (a shift of 100 bytes over a 1 GiB window: 10 M calls), so small shifts are one kernel that walks backwards
         const size_t shift = (size_t)tail - WIN_HEAD;
-        for (size_t done = 0; done < fresh;) {
-            const size_t n = fresh - done < shift ? fresh - done : shift;
-            const size_t src = WIN_HEAD + fresh - done - n;
-            INF_HIP(hipMemcpyAsync(h->win[to].buf + src + shift, h->win[to].buf + src, n, hipMemcpyDeviceToDevice, h->st[1]));
-            done += n;
+        if (shift >= (1u << 20)) {
+            for (size_t done = 0; done < fresh;) {
+                const size_t n = fresh - done < shift ? fresh - done : shift;
+                const size_t src = WIN_HEAD + fresh - done - n;
+                INF_HIP(hipMemcpyAsync(h->win[to].buf + src + shift, h->win[to].buf + src, n, hipMemcpyDeviceToDevice, h->st[1]));
+                done += n;
+            }
+        } else if (fresh) {
+            hipLaunchKernelGGL(k_move_up, dim3(1), dim3(MOVE_THREADS), 0, h->st[1], h->win[to].buf, (size_t)WIN_HEAD, fresh, shift);
+            INF_HIP(hipGetLastError());
         }
         INF_HIP(hipMemcpyAsync(h->win[to].buf, h->win[from].buf + h->win[from].consumed, tail, hipMemcpyDeviceToDevice, h->st[1]));
         INF_HIP(hipStreamSynchronize(h->st[1]));

@@ -75,30 +75,38 @@ static void kill_kids(void)
         if (kids[i] > 0) kill(kids[i], SIGTERM);
 }
 
-/* rank 0: a rank that leaves with an error ends the job (the others would wait for it in the exchange) */
+/* rank 0: a rank that leaves with an error ends the job (the others would wait for it in the exchange). Only the ranks'
+ * own pids are waited for: a waitpid(-1) here also reaped the decompressor children of tables.c, whose owner then could not
+ * learn how they ended. */
 static void *watch_main(void *arg)
 {
     (void)arg;
     for (int left = n_kids; left > 0;) {
-        int st = 0;
-        const pid_t p = waitpid(-1, &st, 0);
-        if (p < 0) {
-            if (errno == EINTR) continue;
-            break;
+        int progressed = 0;
+        for (int i = 0; i < n_kids; i++) {
+            if (kids[i] <= 0) continue;
+            int st = 0;
+            const pid_t p = waitpid(kids[i], &st, WNOHANG);
+            if (p == 0) continue;
+            if (p < 0) {
+                if (errno == EINTR) continue;
+                kids[i] = 0;                                         /* not ours to wait for any more */
+                left--;
+                progressed = 1;
+                continue;
+            }
+            kids[i] = 0;
+            left--;
+            progressed = 1;
+            if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
+                fprintf(itx_err_stream ? itx_err_stream : stderr, "[iteres] rank %d left with %s %d: the job ends here\n", i + 1,
+                        WIFEXITED(st) ? "status" : "signal", WIFEXITED(st) ? WEXITSTATUS(st) : WTERMSIG(st));
+                kill_kids();
+                fflush(NULL);
+                _exit(255);
+            }
         }
-        int mine = -1;
-        for (int i = 0; i < n_kids; i++)
-            if (kids[i] == p) mine = i;
-        if (mine < 0) continue;                                     /* some other child of this process (a decompressor) */
-        kids[mine] = 0;
-        left--;
-        if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
-            fprintf(itx_err_stream ? itx_err_stream : stderr, "[iteres] rank %d left with %s %d: the job ends here\n", mine + 1,
-                    WIFEXITED(st) ? "status" : "signal", WIFEXITED(st) ? WEXITSTATUS(st) : WTERMSIG(st));
-            kill_kids();
-            fflush(NULL);
-            _exit(255);
-        }
+        if (!progressed && left > 0) usleep(2000);
     }
     kids_done = 1;
     return NULL;
@@ -172,6 +180,16 @@ void multi_begin(int splittable, const char *aln_arg, int multi_file)
     int n;
     if (g && *g && strcmp(g, "all") != 0) {
         n = atoi(g);
+        /* no more ranks than devices (every extra rank would die in hipSetDevice and end the job) — unless a device map says
+         * where the ranks go (ITX_GPU_MAP: rehearsals with ranks that share a card) */
+        if (n > 1 && !(getenv("ITX_GPU_MAP") && *getenv("ITX_GPU_MAP"))) {
+            int have = count_gpus_sysfs();
+            if (have == 0) have = probe_devices();
+            if (n > have) {
+                warnf("[iteres] note: ITX_GPUS=%d but %d device%s visible: running on %d", n, have, have == 1 ? " is" : "s are", have);
+                n = have;
+            }
+        }
     } else {
         n = count_gpus_sysfs();
         if (n == 0) n = probe_devices();

@@ -120,15 +120,63 @@ static size_t warm_input_bytes;               /* size of all alignment files tog
  * over the network interface, one ring per link) and needs nothing of the data — the exchange at the end only joins it. */
 static struct {
     pthread_t th;
-    int on, rc;
+    int on, rc, done;
     itx_comm *comm;
     char err[400];
 } early_comm;
+static char warm_err[400];                    /* the helper thread's last error (itx_last_error is per thread) */
+/* Which way the partials travel is agreed on by ALL ranks: every rank leaves a marker next to the communicator id when its
+ * attempt at an RCCL communicator has ended — "ok" or "fail" — and the exchange is RCCL only when every marker says ok. A
+ * rank that fails alone (its device, its copy of the library, the id file) would otherwise switch to files while the others
+ * sit in ncclCommInitRank / ncclReduce, which have no timeout. */
+static void comm_marker_path(char *buf, size_t n, int rank) { snprintf(buf, n, "%s.st%d", multi_comm_id(), rank); }
+static void comm_marker_write(int ok)
+{
+    if (multi_world() <= 1) return;
+    char path[700], tmp[720];
+    comm_marker_path(path, sizeof path, multi_rank());
+    snprintf(tmp, sizeof tmp, "%s.tmp", path);
+    FILE *f = fopen(tmp, "w");
+    if (!f) return;
+    fputs(ok ? "ok" : "fail", f);
+    if (fclose(f) == 0 && rename(tmp, path) != 0) unlink(tmp);
+}
+/* 1: every rank has a communicator; 0: some rank has none (all take the files); -1: a marker never came */
+static int comm_agree(double timeout_s)
+{
+    const double t0 = now_s();
+    for (unsigned spins = 0;; spins++) {
+        int n_ok = 0;
+        for (int r = 0; r < multi_world(); r++) {
+            char path[700], w[8] = {0};
+            comm_marker_path(path, sizeof path, r);
+            FILE *f = fopen(path, "r");
+            if (!f) continue;
+            const size_t k = fread(w, 1, 7, f);
+            fclose(f);
+            if (k >= 4 && memcmp(w, "fail", 4) == 0) return 0;
+            if (k >= 2 && memcmp(w, "ok", 2) == 0) n_ok++;
+        }
+        if (n_ok == multi_world()) return 1;
+        if (now_s() - t0 > timeout_s) return -1;
+        usleep(spins < 2000 ? 200 : 2000);
+    }
+}
+static void comm_markers_remove(void)
+{
+    for (int r = 0; r < multi_world(); r++) {
+        char path[700];
+        comm_marker_path(path, sizeof path, r);
+        unlink(path);
+    }
+}
 static void *early_comm_main(void *arg)
 {
     (void)arg;
     early_comm.rc = itx_comm_create(multi_rank(), multi_world(), multi_device(), multi_comm_id(), ITX_COMM_RCCL, &early_comm.comm);
     if (early_comm.rc != ITX_OK) snprintf(early_comm.err, sizeof early_comm.err, "%s", itx_last_error());
+    comm_marker_write(early_comm.rc == ITX_OK);
+    __atomic_store_n(&early_comm.done, 1, __ATOMIC_RELEASE);
     return NULL;
 }
 
@@ -142,7 +190,12 @@ static void *warm_main(void *arg)
         pthread_create(&early_comm.th, NULL, early_comm_main, NULL) == 0)
         early_comm.on = 1;
     double t_created = b, t_pinned = b;
-    if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && itx_inflater_create(multi_device(), &g_inflater) == ITX_OK) {
+    int inf_rc = ITX_OK;
+    if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && (inf_rc = itx_inflater_create(multi_device(), &g_inflater)) != ITX_OK)
+        snprintf(warm_err, sizeof warm_err, "%s", itx_last_error());
+    else if (ndev <= 0)
+        snprintf(warm_err, sizeof warm_err, "no usable GPU (%s)", itx_last_error());
+    if (g_inflater) {
         t_created = now_s();
         /* the compressed chunks the reader rotates through (one being read, the others being decoded) */
         const char *ce = getenv("ITX_BGZF_CHUNK");
@@ -404,7 +457,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     gpu_warmup_join();
     if (timing) fprintf(stderr, "[itx timing] waited %.3f s for the helper thread\n", now_s() - t_join);
     if (g_inflater) use_device_reader();
-    if (shared && !g_inflater) die("rank %d: the device decoder did not come up: %s", rank, itx_last_error());
+    if (shared && !g_inflater) die("rank %d: the device decoder did not come up: %s", rank, warm_err[0] ? warm_err : itx_last_error());
     /* pass 0: this rank's shares, then the exchange. pass 1 (rank 0 only, and only when a share boundary did not hold —
      * the split points are guesses that the rank before verifies): the whole job again by this rank alone */
     for (int pass = 0; pass < 2; pass++) {
@@ -651,7 +704,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             }
             pend[k] = 0;
         }
-        fprintf(stderr, "\r* Processed read ends: %llu\n", ends);
+        /* a share of a multi-rank job: the line with the whole job's count comes after the exchange (rank 0's share alone
+         * would differ from what the reference prints) */
+        if (!(shared && pass == 0)) fprintf(stderr, "\r* Processed read ends: %llu\n", ends);
         if (timing)
             fprintf(stderr, "[itx timing] stream of %s: decode %.3f s, host passes %.3f s, submit %.3f s, waiting for the device %.3f s\n", files[fi],
                     t_read, t_host, t_submit, t_wait);
@@ -680,21 +735,48 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         itx_comm *comm = NULL;
         const double tc = now_s();
         int comm_mode = multi_comm_mode();
-        int crc;
-        if (early_comm.on) {                                         /* under way since the start of the run */
-            pthread_join(early_comm.th, NULL);
-            early_comm.on = 0;
-            crc = early_comm.rc;
-            comm = early_comm.comm;
-            if (crc != ITX_OK) warnf("[iteres] note: %s", early_comm.err);
+        int crc = ITX_OK;
+        if (comm_mode == ITX_COMM_RCCL) {
+            if (!early_comm.on) {                                    /* not under way since the start of the run: make it now, same thread function */
+                if (pthread_create(&early_comm.th, NULL, early_comm_main, NULL) == 0) {
+                    early_comm.on = 1;
+                } else {
+                    early_comm.rc = ITX_E_STATE;
+                    snprintf(early_comm.err, sizeof early_comm.err, "no thread for the communicator");
+                    comm_marker_write(0);
+                    early_comm.done = 1;
+                }
+            }
+            const char *te = getenv("ITX_COMM_TIMEOUT");
+            int agreed;
+            if (world > 1) {
+                agreed = comm_agree(te && atof(te) > 0 ? atof(te) : 900.0);
+            } else {                                                 /* ITX_COMM_SELFTEST: a job of one rank agrees with itself */
+                if (early_comm.on) pthread_join(early_comm.th, NULL);
+                early_comm.on = 0;
+                agreed = early_comm.rc == ITX_OK;
+            }
+            if (agreed < 0) die("rank %d: the other ranks never said whether they have a communicator (a rank of the job has died?)", rank);
+            if (agreed == 1 || __atomic_load_n(&early_comm.done, __ATOMIC_ACQUIRE)) {
+                if (early_comm.on) pthread_join(early_comm.th, NULL);
+                early_comm.on = 0;
+                crc = early_comm.rc;
+                comm = early_comm.comm;
+            } else {
+                early_comm.on = 0;                                   /* still inside ncclCommInitRank, waiting for a rank that will not come: left behind */
+                crc = ITX_E_STATE;
+            }
+            if (agreed == 0) {
+                /* some rank has no RCCL communicator (no usable network interface for its bootstrap, its device, its library):
+                 * every rank has seen the same markers and hands its partial over through files — slower, same sums */
+                if (early_comm.err[0]) warnf("[iteres] note: no RCCL communicator (%s); the ranks exchange through files instead", early_comm.err);
+                else warnf("[iteres] note: another rank has no RCCL communicator; the ranks exchange through files instead");
+                if (crc == ITX_OK && comm) itx_comm_destroy(comm);
+                comm = NULL;
+                comm_mode = ITX_COMM_FILE;
+                crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
+            }
         } else {
-            crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
-        }
-        if (crc != ITX_OK && comm_mode == ITX_COMM_RCCL) {
-            /* no RCCL communicator (no usable network interface for its bootstrap, say): the environment is the same for every
-             * rank, so they all end up here and hand their partials over through files — slower, same sums */
-            warnf("[iteres] note: no RCCL communicator (%s); the ranks exchange through files instead", early_comm.err[0] ? early_comm.err : itx_last_error());
-            comm_mode = ITX_COMM_FILE;
             crc = itx_comm_create(rank, world, multi_device(), multi_comm_id(), comm_mode, &comm);
         }
         chk(crc, "itx_comm_create");
@@ -704,6 +786,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             fprintf(stderr, "[itx timing] exchange (%s): export %.3f s, communicator %.3f s, reduce of %.1f MB per rank (waits for the slowest rank) %.3f s\n",
                     comm_mode == ITX_COMM_FILE ? "files" : "RCCL", tc - tx, ty - tc, (double)(n64 * 8 + n32 * 4) / 1e6, now_s() - ty);
         itx_comm_destroy(comm);
+        if (rank == 0 && world > 1) comm_markers_remove();          /* every rank has read them: its partial is here */
         if (rank > 0) {                                              /* handed over: rank 0 writes the files */
             fflush(NULL);
             _exit(0);
@@ -713,6 +796,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             hc->dup_unique = meta[1];
         }
         boundary_missed = meta[2];
+        if (shared && !boundary_missed) fprintf(stderr, "\r* Processed read ends: %llu\n", (unsigned long long)meta[3]);
         if (!boundary_missed) {
             g_reduced_u64 = p64;
             g_reduced_u32 = p32;

@@ -241,3 +241,31 @@ def test_rank0_without_rccl_sends_the_others_to_the_files(exe, big_case, tmp_pat
     assert time.time() - t0 < 60                                    # nobody sat out a timeout
     assert "exchange (files)" in errs[0] and "could not make a communicator id" in errs[1], errs
     _same_dir(ref_dir, str(tmp_path / "rank0"))
+
+
+def test_a_later_rank_without_rccl_takes_every_rank_to_the_files(exe, big_case, tmp_path):
+    """The other way round: rank 0 has its library and is already inside ncclCommInitRank — which has no timeout — when
+    rank 1 finds it cannot load RCCL. Every rank leaves an ok / fail marker next to the communicator id when its attempt has
+    ended and RCCL is used only if all say ok: rank 0 sees rank 1's "fail", leaves its communicator thread behind and both
+    exchange through files, at once. Same files as one rank; the markers are gone afterwards."""
+    d = big_case
+    aln = str(d / "a.bam")
+    ref_dir = str(tmp_path / "plain")
+    _run(exe, ["stat", "-w"], d, aln, ref_dir, dict(os.environ))
+    args = [exe, "stat", "-w", "-o", "out", str(d / "chrom.sizes"), str(d / "rep.sizes"), str(d / "rmsk.txt"), aln]
+    procs = []
+    t0 = time.time()
+    for r in range(2):
+        out = tmp_path / f"rank{r}"
+        out.mkdir()
+        env = dict(os.environ, ITX_RANK=str(r), ITX_WORLD="2", ITX_DEVICE="0", ITX_COMM_ID=str(tmp_path / "job.id"), ITX_EXCHANGE="rccl",
+                   ITX_SPLIT_MIN="1", ITX_TIMING="1", ITX_COMM_TIMEOUT="100")
+        if r == 1:
+            env["ITX_COMM_NO_RCCL"] = "1"
+        procs.append(subprocess.Popen(args, cwd=out, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    errs = [p.communicate(timeout=300)[1] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], errs
+    assert time.time() - t0 < 60                                    # nobody sat out a timeout
+    assert "exchange (files)" in errs[0] and "cannot load librccl" in errs[1], errs
+    _same_dir(ref_dir, str(tmp_path / "rank0"))
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("job.id")], os.listdir(tmp_path)

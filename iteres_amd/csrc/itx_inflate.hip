@@ -23,7 +23,10 @@ static __device__ inline uint32_t itxi_scan_add(uint32_t v, uint32_t lane)
     return v;
 }
 #define ITXI_SCAN_ADD(v, lane) itxi_scan_add(v, lane)
-#define ITXI_NEXT(v, lane) ((lane) < 63u ? (uint32_t)__shfl_down((int32_t)(v), 1, 64) : 0u)
+#define ITXI_LANE_READ(v, j) ((uint32_t)__builtin_amdgcn_ds_bpermute((int32_t)((j) << 2), (int32_t)(v)))
+#define ITXI_BALLOT(p) ((uint64_t)__ballot(p))
+#define ITXI_MBCNT(m, lane) ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)((m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
+#define ITXI_LDS_OR(ptr, v) ((void)atomicOr((ptr), (v)))
 #define ITXI_AT(p, i) (p)[(i) * 64u + ln]          /* a decoder's table element i: lane-interleaved (bank = lane) */
 #define ITXI_BITREV32(x) __builtin_bitreverse32(x)
 typedef uint16_t itxi_u16x2 __attribute__((ext_vector_type(2)));
@@ -56,12 +59,11 @@ static __device__ inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
 
 #define BGZF_HEADER 18u      /* gzip header with the one "BC" extra field (bgzf.c:401-411) */
 #define BGZF_TRAILER 8u      /* CRC32 + ISIZE */
-#define LIT_STRIDE (ITXI_MAX_BLOCK + 16u)         /* bytes of literal scratch per block (the stage reads 16 at a time) */
-#define TOK_STRIDE (2u * ITXI_MAX_TOK)            /* words of token scratch per block */
+#define SCR_STRIDE ITXI_REGION                    /* bytes of scratch per block: literals from its bottom, tokens from its top (itx_inflate_core.h) */
 
-// pass 1: lane = block. meta[3b] = status, [3b+1] = literals, [3b+2] = matches
-__global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp, const itx_bgzf_block *__restrict__ blk, uint32_t n, uint8_t *__restrict__ lit,
-                                               uint32_t *__restrict__ tok, uint32_t *__restrict__ meta)
+// pass 1: lane = block. meta[3b] = status, [3b+1] = literals, [3b+2] = tokens
+__global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp, const itx_bgzf_block *__restrict__ blk, uint32_t n, uint8_t *__restrict__ scr,
+                                               uint32_t *__restrict__ meta)
 {
     __shared__ uint32_t s_lhi[9 * 64];
     __shared__ uint16_t s_offs[16 * 64], s_loffs[16 * 64], s_doffs[16 * 64];
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp
     if (b >= n) return;
     const uint32_t coff = blk[b].coff, csize = blk[b].csize, usize = blk[b].usize;
     ItxiTab T{s_lsym8, s_lhi, s_dsym, s_offs, s_loffs, s_doffs, s_lens};
-    ItxiTokens K{lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, 0, 0};
+    uint8_t *region = scr + (size_t)b * SCR_STRIDE;
+    ItxiTokens K{region, reinterpret_cast<uint32_t *>(region + SCR_STRIDE), 0, 0};
     int rc = ITXI_E_INPUT;
     if (csize >= BGZF_HEADER + BGZF_TRAILER + 2u && usize <= ITXI_MAX_BLOCK)
         rc = itxi_tokens(T, ln, comp, coff + BGZF_HEADER, coff + csize - BGZF_TRAILER, usize, K);
@@ -80,44 +83,20 @@ __global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp
 }
 
 // pass 2: wave = block
-__global__ __launch_bounds__(64) void k_resolve(const itx_bgzf_block *__restrict__ blk, uint32_t first, uint32_t n, const uint8_t *__restrict__ lit,
-                                                const uint32_t *__restrict__ tok, const uint32_t *__restrict__ meta, uint8_t *__restrict__ out,
-                                                uint8_t *__restrict__ status)
+__global__ __launch_bounds__(64) void k_resolve(const itx_bgzf_block *__restrict__ blk, uint32_t first, uint32_t n, const uint8_t *__restrict__ scr,
+                                                const uint32_t *__restrict__ meta, uint8_t *__restrict__ out, uint8_t *__restrict__ status)
 {
-    __shared__ uint32_t s_mem[(ITXI_RING + ITXI_LSTAGE) / 4];           // the ring, and right behind it the literal stage
-    uint32_t *s_ring = s_mem, *s_stage = s_mem + ITXI_RING / 4;
+    __shared__ uint32_t s_mem[(ITXI_RING + ITXI_LSTAGE + ITXI_BMAP / 8u + 8u) / 4];       // the ring, right behind it the literal stage, then the bitmap of token starts
+    uint32_t *s_ring = s_mem, *s_stage = s_mem + ITXI_RING / 4, *s_bmap = s_mem + (ITXI_RING + ITXI_LSTAGE) / 4;
     if (blockIdx.x >= n) return;
     const uint32_t b = first + blockIdx.x;
     int rc = (int)meta[3 * b];
-    if (rc == ITXI_OK)
-        rc = itxi_resolve(s_ring, s_stage, lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, meta[3 * b + 1], meta[3 * b + 2], out, blk[b].uoff, blk[b].usize,
-                          threadIdx.x);
-    if (threadIdx.x == 0) status[b] = (uint8_t)rc;
-}
-
-// pass 2 as the pushes run it: a fixed set of waves that take blocks off a counter. ONE workgroup of RES_WAVES waves per
-// CU, holding RES_WAVES x 6 KB of LDS — which leaves a CU room for one pass-1 workgroup (68 KB) beside it. Launched one
-// wave per block instead, pass 2 keeps every CU's LDS full of its own 6-KB workgroups, a 68-KB hole never opens, and the
-// pass 1 of the next chunk only starts when the pass 2 of this one has drained: the two passes of different chunks, which
-// are both latency-bound and want to run side by side, took turns (measured: a chunk every 21 ms with two pushes in flight,
-// the sum of its two passes).
-#define RES_WAVES 14u
-__global__ __launch_bounds__(RES_WAVES * 64u) void k_resolve_p(const itx_bgzf_block *__restrict__ blk, uint32_t n, const uint8_t *__restrict__ lit,
-                                                               const uint32_t *__restrict__ tok, const uint32_t *__restrict__ meta, uint8_t *__restrict__ out,
-                                                               uint8_t *__restrict__ status, uint32_t *__restrict__ next)
-{
-    __shared__ uint32_t s_mem[RES_WAVES][(ITXI_RING + ITXI_LSTAGE) / 4];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    (void)next;
-    const uint32_t stride = gridDim.x * RES_WAVES;
-    // blocks dealt to the waves in turn (they cost about the same: BGZF blocks are cut by size)
-    for (uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(blockIdx.x * RES_WAVES + wv)); b < n; b += stride) {
-        int rc = (int)meta[3 * b];
-        if (rc == ITXI_OK)
-            rc = itxi_resolve(s_mem[wv], s_mem[wv] + ITXI_RING / 4, lit + (size_t)b * LIT_STRIDE, tok + (size_t)b * TOK_STRIDE, meta[3 * b + 1], meta[3 * b + 2], out, blk[b].uoff,
-                              blk[b].usize, lane);
-        if (lane == 0) status[b] = (uint8_t)rc;
+    if (rc == ITXI_OK) {
+        const uint8_t *region = scr + (size_t)b * SCR_STRIDE;
+        rc = itxi_resolve(s_ring, s_stage, s_bmap, region, reinterpret_cast<const uint32_t *>(region + SCR_STRIDE), meta[3 * b + 1], meta[3 * b + 2], out, blk[b].uoff,
+                          blk[b].usize, threadIdx.x);
     }
+    if (threadIdx.x == 0) status[b] = (uint8_t)rc;
 }
 
 // =====================================================================================================================
@@ -347,14 +326,13 @@ static void report_at_exit();
 struct itx_inflater {
     int device;
     hipStream_t st[2];
-    hipStream_t st_res;                    // every push's pass 2, one after the other (see k_resolve_p)
     uint8_t *arena;                        // itx_inflater_reserve: the one allocation the lanes' and the first n_reserved_win windows' buffers are cut from
     int n_reserved_win;
     int n_cu;
-    uint8_t *d_comp, *d_out, *d_status, *d_lit;
-    uint32_t *d_tok, *d_meta;
+    uint8_t *d_comp, *d_out, *d_status, *d_lit;      // d_lit: the blocks' scratch regions (SCR_STRIDE bytes each)
+    uint32_t *d_meta;
     itx_bgzf_block *d_blk;
-    size_t comp_cap, out_cap, status_cap, blk_cap, lit_cap, tok_cap, meta_cap;
+    size_t comp_cap, out_cap, status_cap, blk_cap, lit_cap, meta_cap;
     hipEvent_t ev[4];
     float ms_tokens, ms_resolve, ms_resolve_all;
     hipEvent_t ev_res_end[2];
@@ -370,11 +348,10 @@ struct itx_inflater {
         hipEvent_t copied;                 // the compressed bytes have left the caller's buffer
         hipEvent_t ev[3];                  // ITX_TIMING: before pass 1, between the passes, after pass 2
         hipEvent_t p1_done, done;          // pass 1 through (the shared pass-2 stream waits for it); the whole push through
-        uint32_t *d_next;                  // pass 2's block counter
         uint8_t *d_comp, *d_status, *d_lit, *h_status;
-        uint32_t *d_tok, *d_meta;
+        uint32_t *d_meta;
         itx_bgzf_block *d_blk, *h_blk;     // h_blk (page-locked): the block list shifted to the window's offsets
-        size_t comp_cap, status_cap, lit_cap, tok_cap, meta_cap, blk_cap, h_cap;
+        size_t comp_cap, status_cap, lit_cap, meta_cap, blk_cap, h_cap;
         size_t n_blk, total;
         int busy;
     } lane[ITX_BAMWIN_LANES];
@@ -428,10 +405,8 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
         for (int q = 0; q < 3; q++) INF_HIP(hipEventCreate(&h->lane[k].ev[q]));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].p1_done, hipEventDisableTiming));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].done, hipEventDisableTiming));
-        INF_HIP(hipMalloc((void **)&h->lane[k].d_next, 16));
     }
     SETUP_TICK("lane streams, events, counters");
-    INF_HIP(hipStreamCreateWithFlags(&h->st_res, hipStreamNonBlocking));
     h->n_cu = 256;
     if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
     if (getenv("ITX_TIMING")) {
@@ -464,13 +439,8 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_status);
     (void)hipFree(h->d_blk);
     (void)hipFree(h->d_lit);
-    (void)hipFree(h->d_tok);
     (void)hipFree(h->d_meta);
     for (int k = h->arena ? h->n_reserved_win : 0; k < ITX_BAMWIN_WINDOWS; k++) (void)hipFree(h->win[k].buf);
-    if (h->st_res) {
-        (void)hipStreamSynchronize(h->st_res);
-        (void)hipStreamDestroy(h->st_res);
-    }
     for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
         if (h->lane[k].st) {
             (void)hipStreamSynchronize(h->lane[k].st);
@@ -481,12 +451,10 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
             if (h->lane[k].ev[q]) (void)hipEventDestroy(h->lane[k].ev[q]);
         if (h->lane[k].p1_done) (void)hipEventDestroy(h->lane[k].p1_done);
         if (h->lane[k].done) (void)hipEventDestroy(h->lane[k].done);
-        (void)hipFree(h->lane[k].d_next);
         if (!h->arena) {
             (void)hipFree(h->lane[k].d_comp);
             (void)hipFree(h->lane[k].d_status);
             (void)hipFree(h->lane[k].d_lit);
-            (void)hipFree(h->lane[k].d_tok);
             (void)hipFree(h->lane[k].d_meta);
             (void)hipFree(h->lane[k].d_blk);
         }
@@ -593,15 +561,14 @@ extern "C" int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_l
     if ((rc = grow(&h->d_out, &h->out_cap, out_len + 64)) != ITX_OK) return rc;
     if ((rc = grow(&h->d_status, &h->status_cap, n_blk)) != ITX_OK) return rc;
     if ((rc = grow(&h->d_blk, &h->blk_cap, n_blk)) != ITX_OK) return rc;
-    if ((rc = grow(&h->d_lit, &h->lit_cap, n_blk * (size_t)LIT_STRIDE)) != ITX_OK) return rc;
-    if ((rc = grow(&h->d_tok, &h->tok_cap, n_blk * (size_t)TOK_STRIDE)) != ITX_OK) return rc;
+    if ((rc = grow(&h->d_lit, &h->lit_cap, n_blk * (size_t)SCR_STRIDE)) != ITX_OK) return rc;
     if ((rc = grow(&h->d_meta, &h->meta_cap, 3 * n_blk)) != ITX_OK) return rc;
     // pass 1 over all blocks at once (a lane per block: it takes many blocks to fill the chip)
     INF_HIP(hipMemcpyAsync(h->d_blk, blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, h->st[0]));
     INF_HIP(hipMemcpyAsync(h->d_comp, comp, comp_len, hipMemcpyHostToDevice, h->st[0]));
     INF_HIP(hipEventRecord(h->ev[0], h->st[0]));
     hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, h->st[0], (const uint32_t *)h->d_comp, h->d_blk, (uint32_t)n_blk, h->d_lit,
-                       h->d_tok, h->d_meta);
+                       h->d_meta);
     INF_HIP(hipGetLastError());
     INF_HIP(hipEventRecord(h->ev[1], h->st[0]));
     INF_HIP(hipStreamSynchronize(h->st[0]));
@@ -611,7 +578,7 @@ extern "C" int itx_inflate_bgzf(itx_inflater *h, const void *comp, size_t comp_l
     INF_HIP(hipEventRecord(h->ev[2], h->st[0]));
     for (size_t b0 = 0; b0 < n_blk; b0 += per, s ^= 1) {
         const size_t b1 = b0 + per < n_blk ? b0 + per : n_blk;
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)(b1 - b0)), dim3(64), 0, h->st[s], h->d_blk, (uint32_t)b0, (uint32_t)(b1 - b0), h->d_lit, h->d_tok, h->d_meta,
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)(b1 - b0)), dim3(64), 0, h->st[s], h->d_blk, (uint32_t)b0, (uint32_t)(b1 - b0), h->d_lit, h->d_meta,
                            h->d_out, h->d_status);
         INF_HIP(hipGetLastError());
         if (b0 == 0) INF_HIP(hipEventRecord(h->ev[3], h->st[0]));
@@ -711,33 +678,20 @@ extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *
     if ((rc = grow(&Ln.d_comp, &Ln.comp_cap, comp_len + 64)) != ITX_OK) return rc;
     if ((rc = grow(&Ln.d_status, &Ln.status_cap, n_blk)) != ITX_OK) return rc;
     if ((rc = grow(&Ln.d_blk, &Ln.blk_cap, n_blk)) != ITX_OK) return rc;
-    if ((rc = grow(&Ln.d_lit, &Ln.lit_cap, n_blk * (size_t)LIT_STRIDE)) != ITX_OK) return rc;
-    if ((rc = grow(&Ln.d_tok, &Ln.tok_cap, n_blk * (size_t)TOK_STRIDE)) != ITX_OK) return rc;
+    if ((rc = grow(&Ln.d_lit, &Ln.lit_cap, n_blk * (size_t)SCR_STRIDE)) != ITX_OK) return rc;
     if ((rc = grow(&Ln.d_meta, &Ln.meta_cap, 3 * n_blk)) != ITX_OK) return rc;
     hipStream_t st = Ln.st;
     INF_HIP(hipMemcpyAsync(Ln.d_blk, Ln.h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, st));
     INF_HIP(hipMemcpyAsync(Ln.d_comp, comp, comp_len, hipMemcpyHostToDevice, st));
     INF_HIP(hipEventRecord(Ln.copied, st));
     INF_HIP(hipEventRecord(Ln.ev[0], st));
-    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta);
+    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, Ln.d_lit, Ln.d_meta);
     INF_HIP(hipGetLastError());
-    // pass 2: by default on the push's own stream, one wave per block (scratch experiments: ITX_RES_SHARED=1 runs every push's
-    // pass 2 on one shared stream, ITX_RES_PERSIST=1 with a fixed set of waves — neither paid)
-    static const int res_shared = getenv("ITX_RES_SHARED") != nullptr, res_persist = getenv("ITX_RES_PERSIST") != nullptr;
+    // pass 2 on the push's own stream, one wave per block (every push's pass 2 on one shared stream, or a fixed set of waves
+    // that take blocks in turn, were measured slower: DESIGN.md)
     hipStream_t sr = st;
-    if (res_shared || res_persist) {
-        sr = h->st_res;
-        INF_HIP(hipEventRecord(Ln.p1_done, st));
-        INF_HIP(hipStreamWaitEvent(sr, Ln.p1_done, 0));
-    }
     INF_HIP(hipEventRecord(Ln.ev[1], sr));
-    if (res_persist) {
-        const unsigned res_wgs = (unsigned)((n_blk + RES_WAVES - 1) / RES_WAVES) < (unsigned)h->n_cu ? (unsigned)((n_blk + RES_WAVES - 1) / RES_WAVES) : (unsigned)h->n_cu;
-        hipLaunchKernelGGL(k_resolve_p, dim3(res_wgs), dim3(RES_WAVES * 64u), 0, sr, Ln.d_blk, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta, h->win[w].buf, Ln.d_status,
-                           Ln.d_next);
-    } else {
-        hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, sr, Ln.d_blk, 0u, (uint32_t)n_blk, Ln.d_lit, Ln.d_tok, Ln.d_meta, h->win[w].buf, Ln.d_status);
-    }
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, sr, Ln.d_blk, 0u, (uint32_t)n_blk, Ln.d_lit, Ln.d_meta, h->win[w].buf, Ln.d_status);
     INF_HIP(hipGetLastError());
     INF_HIP(hipEventRecord(Ln.ev[2], sr));
     INF_HIP(hipMemcpyAsync(Ln.h_status, Ln.d_status, n_blk, hipMemcpyDeviceToHost, sr));
@@ -802,9 +756,9 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
     // ONE allocation for all of it: on some hosts every hipMalloc costs ~15 ms whatever its size (and holds up the other
     // threads' HIP calls meanwhile) — seventy of them were 1.2 s of a 4 s run
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t sz_comp = al(comp_bytes + 64), sz_status = al(max_blocks), sz_blk = al(max_blocks * sizeof(itx_bgzf_block)), sz_lit = al(max_blocks * (size_t)LIT_STRIDE),
-                 sz_tok = al(max_blocks * (size_t)TOK_STRIDE * 4), sz_meta = al(3 * max_blocks * 4);
-    const size_t lane_bytes = sz_comp + sz_status + sz_blk + sz_lit + sz_tok + sz_meta;
+    const size_t sz_comp = al(comp_bytes + 64), sz_status = al(max_blocks), sz_blk = al(max_blocks * sizeof(itx_bgzf_block)), sz_lit = al(max_blocks * (size_t)SCR_STRIDE),
+                 sz_meta = al(3 * max_blocks * 4);
+    const size_t lane_bytes = sz_comp + sz_status + sz_blk + sz_lit + sz_meta;
     const size_t total = lane_bytes * ITX_BAMWIN_LANES + per * n;
     uint8_t *base = nullptr;
     const double t0 = wall_now();
@@ -823,8 +777,7 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
         Ln.d_comp = p; p += sz_comp; Ln.comp_cap = comp_bytes + 64;
         Ln.d_status = p; p += sz_status; Ln.status_cap = max_blocks;
         Ln.d_blk = (itx_bgzf_block *)p; p += sz_blk; Ln.blk_cap = max_blocks;
-        Ln.d_lit = p; p += sz_lit; Ln.lit_cap = max_blocks * (size_t)LIT_STRIDE;
-        Ln.d_tok = (uint32_t *)p; p += sz_tok; Ln.tok_cap = max_blocks * (size_t)TOK_STRIDE;
+        Ln.d_lit = p; p += sz_lit; Ln.lit_cap = max_blocks * (size_t)SCR_STRIDE;
         Ln.d_meta = (uint32_t *)p; p += sz_meta; Ln.meta_cap = 3 * max_blocks;
         if (Ln.h_cap < max_blocks) {
             if (Ln.h_blk) (void)hipHostFree(Ln.h_blk);

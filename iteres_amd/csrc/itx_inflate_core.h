@@ -27,10 +27,11 @@
 //
 // Hooks the including file defines: ITXI_FN (function attributes), ITXI_WAVE (lanes that share pass 2: 64 / 1),
 // ITXI_UNI(x) (pass 2: a wave-uniform value as such), ITXI_AT(p, i) (pass 1: element i of a per-decoder table: lane-
-// interleaved on the device, using the lane id `ln` in scope), ITXI_BCAST(v, j) (pass 2: lane j's v, for all),
+// interleaved on the device, using the lane id `ln` in scope), ITXI_BCAST(v, j) (pass 2: lane j's v, for all; j uniform),
+// ITXI_LANE_READ(v, j) (pass 2: lane j's v with j per lane), ITXI_BALLOT(p) (pass 2: 64-bit mask of the lanes where p holds),
+// ITXI_MBCNT(m, lane) (set bits of m below `lane`), ITXI_LDS_OR(ptr, v) (pass 2: atomic OR into the wave's LDS),
 // ITXI_BITREV32(x), ITXI_PKSIGN16(a, b) (bit 15 of a - b in each 16-bit half, moved to bits 0 and 16), ITXI_LOADW / ITXI_LOADB
-// (global loads), ITXI_FENCE(), ITXI_SCAN_ADD(v, lane) (pass 2: inclusive prefix sum of v over the lanes), ITXI_NEXT(v, lane) (pass 2: the next
-// lane's v, 0 for the last lane).
+// (global loads), ITXI_FENCE(), ITXI_SCAN_ADD(v, lane) (pass 2: inclusive prefix sum of v over the lanes).
 #pragma once
 #include <stdint.h>
 
@@ -55,7 +56,16 @@
 #define ITXI_NEAR (ITXI_RING - 320u)       // matches up to this distance read the ring (a match writes at most 258 bytes ahead)
 #define ITXI_LAG 1024u                     // pass 2: full stripes may wait this long for their write-back (+ a stripe + a token < ITXI_NEAR - 258)
 #define ITXI_MAX_BLOCK 65536u              // BGZF: a block inflates to at most 64 KiB
-#define ITXI_MAX_TOK (ITXI_MAX_BLOCK / 3u + 1u)       // a match is at least 3 bytes
+// What pass 1 leaves for pass 2 lives in ONE region of scratch per block: the literal bytes grow up from its bottom, the 4-byte
+// tokens down from its top. A match stands for at least 3 bytes of output and takes 4 bytes of token, a literal takes one, a
+// run token (below) is written once per 256 literals at most: literals + 4 x tokens <= 65536 x 4 / 3 at any moment, so the
+// two never meet in 88 KiB (a quarter megabyte per block when the two had arrays of their own, sized for their worst cases).
+#define ITXI_REGION 90112u                 // bytes per block, a multiple of 16
+#define ITXI_MAX_TOK (ITXI_MAX_BLOCK / 3u + 1u + ITXI_MAX_BLOCK / 256u + 2u)
+// a token: a match as (length - 3) | (distance - 1) << 8 | (literals since the previous token, at most 255) << 23; a longer run of
+// literals gets a token of its own in front: bit 31 | the run
+#define ITXI_TOK_RUN 0x80000000u
+#define ITXI_BMAP 2048u                    // pass 2: bytes of output the fast steps of one batch of tokens may cover (a bitmap of token starts in LDS)
 
 enum {
     ITXI_OK = 0,
@@ -305,16 +315,12 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, bool
     return left;
 }
 
-// What pass 1 leaves for pass 2, per block: lit[0, n_lit) the literal bytes in stream order; tok[0, n_tok) the matches,
-// x = literals since the previous match | length << 16, y = distance; literals after the last match: n_lit - (sum of x's
-// low halves). A stored block's bytes are literals.
-struct __attribute__((aligned(8))) ItxiPair {
-    uint32_t x, y;
-};
-
+// What pass 1 leaves for pass 2, per block (one region, see ITXI_REGION): lit[0, n_lit) the literal bytes in stream order;
+// tok_top[-1 - i], i in [0, n_tok): the tokens; literals after the last token: n_lit - (sum of the tokens' runs). A stored
+// block's bytes are literals.
 struct ItxiTokens {
-    uint8_t *lit;                          // 4-byte aligned, with room for 3 bytes past the last literal
-    uint32_t *tok;                         // pairs (x, y), 8-byte aligned
+    uint8_t *lit;                          // bottom of the region (16-byte aligned)
+    uint32_t *tok_top;                     // its top
     uint32_t n_lit, n_tok;
 };
 
@@ -466,8 +472,12 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
                 if (dist > produced) return ITXI_E_DIST;
                 if (len > usize - produced) return ITXI_E_OUTPUT;
-                ItxiPair *tp = reinterpret_cast<ItxiPair *>(K.tok) + n_tok;
-                ITXI_EXP_STORE(*tp = ItxiPair{run | (len << 16), dist});
+                if (run > 255u) {                                  // (rare: the literals of one token reach beyond its 8 bits)
+                    ITXI_EXP_STORE(*(K.tok_top - 1 - n_tok) = ITXI_TOK_RUN | run);
+                    n_tok++;
+                    run = 0;
+                }
+                ITXI_EXP_STORE(*(K.tok_top - 1 - n_tok) = (len - 3u) | ((dist - 1u) << 8) | (run << 23));
                 n_tok++;
                 run = 0;
                 produced += len;
@@ -567,10 +577,22 @@ ITXI_FN void itxi_literals(uint32_t *ring32, ItxiOut &o, ItxiLit &L, uint32_t lp
 }
 
 // Replays a block's tokens (validated by pass 1: distances inside the block, lengths inside usize) into out[g0, g0 + usize).
-// Tokens are fetched a wave's width at a time, one per lane, the next batch while the current one is replayed. stage32 must
-// lie right behind the ring (ring32 + ITXI_RING / 4).
-ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit, const uint32_t *tok, uint32_t n_lit, uint32_t n_tok, uint8_t *out, uint32_t g0,
-                         uint32_t usize, uint32_t lane)
+// Tokens are fetched a wave's width at a time, one per lane (lane j = token j of the batch), the next batch while the current
+// one is replayed. stage32 must lie right behind the ring (ring32 + ITXI_RING / 4); bmap32: (ITXI_BMAP + 64) / 32 words.
+//
+// Per batch, in the vector pipes: where every token's bytes go and where its literals come from (prefix sums). Then the batch
+// is replayed a WAVE OF BYTES at a time, whatever the tokens' sizes: lane q of a step produces output byte base + q — it finds
+// its token (a bitmap of token starts in LDS, a ballot, a bit count), reads that token's fields from the lane that holds them,
+// and takes its byte from the literal stage or, for a match, from the ring (the few matches that reach further back: from what
+// was written back). A step may only read what earlier steps wrote: it ends in front of the first byte whose source lies inside
+// the step itself (a match right behind its own source; a match that overlaps itself reads its first `distance` bytes again,
+// so it too ends a step at most once). With one token per step — what this loop used to do, a token of 9 bytes on average —
+// most lanes of most steps had nothing to do, and a literal-heavy stream (real qualities: 3 - 4 literals per match) replayed at
+// half the rate of a match-heavy one.
+// Tokens the steps do not take (literals that do not fit the stage in one piece, a token behind the bitmap's reach, damaged
+// values) go the long way round one at a time, as before.
+ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, uint32_t *bmap32, const uint8_t *lit, const uint32_t *tok_top, uint32_t n_lit, uint32_t n_tok, uint8_t *out,
+                         uint32_t g0, uint32_t usize, uint32_t lane)
 {
     uint8_t *ring8 = reinterpret_cast<uint8_t *>(ring32);
     ItxiOut o;
@@ -586,119 +608,127 @@ ITXI_FN int itxi_resolve(uint32_t *ring32, uint32_t *stage32, const uint8_t *lit
     L.n_lit = n_lit;
     uint32_t lp = 0;
     if (n_lit > usize || n_tok > ITXI_MAX_TOK) return ITXI_E_OUTPUT;
-    if (reinterpret_cast<const uint8_t *>(stage32) != ring8 + ITXI_RING) return ITXI_E_OUTPUT;      // the short step reads both through ring8
-    uint32_t nx = 0, nd = 0;
-    if (lane < n_tok) {
-        nx = ITXI_LOADW(tok, 2 * lane);
-        nd = ITXI_LOADW(tok, 2 * lane + 1);
-    }
+    if (reinterpret_cast<const uint8_t *>(stage32) != ring8 + ITXI_RING) return ITXI_E_OUTPUT;      // a step reads both through ring8
+    uint32_t nw = 0;
+    if (lane < n_tok) nw = ITXI_LOADW(tok_top - 1 - lane, 0);
     for (uint32_t t0 = 0; t0 < n_tok; t0 += ITXI_WAVE) {
-        const uint32_t cx = nx, cd = nd;
+        const uint32_t cw = nw;
         const uint32_t tn = t0 + ITXI_WAVE + lane;
-        if (tn < n_tok) {
-            nx = ITXI_LOADW(tok, 2 * tn);
-            nd = ITXI_LOADW(tok, 2 * tn + 1);
-        }
+        if (tn < n_tok) nw = ITXI_LOADW(tok_top - 1 - tn, 0);
         const uint32_t nb = n_tok - t0 < ITXI_WAVE ? n_tok - t0 : ITXI_WAVE;
-        // Per token, in the lanes (lane j = token j of the batch): where its bytes go and where its literals come from (prefix
-        // sums), and whether the SHORT STEP may take it — literals and match together no longer than a wave, the match's source
-        // entirely before the token's own bytes, every guard of the long way round satisfied. The serial
-        // loop below is bound by the CU's scalar unit (measured: 65 scalar instructions per token, the scalar pipe shared by
-        // four SIMDs); what can be worked out for 64 tokens at once in the vector pipes is.
         const bool have = lane < nb;
-        const uint32_t v_run = have ? cx & 0xffffu : 0u, v_len = have ? cx >> 16 : 0u, v_tot = v_run + v_len;
+        const bool is_run = (cw & ITXI_TOK_RUN) != 0;
+        const uint32_t v_run = !have ? 0u : is_run ? cw & ~ITXI_TOK_RUN : (cw >> 23) & 0xffu;
+        const uint32_t v_len = (have && !is_run) ? (cw & 0xffu) + 3u : 0u;
+        const uint32_t cd = (have && !is_run) ? ((cw >> 8) & 0x7fffu) + 1u : 0u;
+        if (ITXI_BALLOT(v_run > ITXI_MAX_BLOCK) != 0) return ITXI_E_OUTPUT;        // (keeps the sums below inside 32 bits whatever the words hold)
+        const uint32_t v_tot = v_run + v_len;
         const uint32_t e_gp = ITXI_SCAN_ADD(v_tot, lane), e_lp = ITXI_SCAN_ADD(v_run, lane);           // inclusive
-        const uint32_t v_gp = o.gp + e_gp - v_tot, v_lp = lp + e_lp - v_run;
-        const uint32_t lit_total = ITXI_BCAST(e_lp, ITXI_WAVE - 1u);
+        const uint32_t v_st = e_gp - v_tot, v_lp = lp + e_lp - v_run;                                  // start of the token's bytes in the batch; of its literals
+        const uint32_t lit_total = ITXI_BCAST(e_lp, ITXI_WAVE - 1u), B = ITXI_BCAST(e_gp, ITXI_WAVE - 1u);
+        const uint32_t gp0 = o.gp;
+        if (lit_total > n_lit - lp || B > o.gend - gp0) return ITXI_E_OUTPUT;
         // the batch's literals staged all at once when they fit (they nearly always do): no refill inside the batch
-        bool staged = false;
-        if (lit_total <= ITXI_LSTAGE - 16u && lp + lit_total <= n_lit) {
-            if (lit_total && (lp < L.base || lp + lit_total > L.base + ITXI_LSTAGE)) itxi_stage_fill(L, lp, lane);
-            staged = true;
-        }
-        const bool v_fast = have && staged && v_len >= 3u && v_len <= 258u && v_tot <= ITXI_WAVE && cd >= v_tot &&
-                            v_gp + v_tot <= o.gend && cd <= v_gp + v_run - o.g0;
-        // bit 31: the short step with the match inside the ring, bit 30: with the match further back (v_tot <= 64 there)
-        const uint32_t v_rt = v_fast ? v_run | (v_tot << 16) | (cd <= ITXI_NEAR ? 0x80000000u : 0x40000000u) : 0u;
+        const bool staged = lit_total <= ITXI_LSTAGE - 16u;
+        if (staged && lit_total && (lp < L.base || lp + lit_total > L.base + ITXI_LSTAGE)) itxi_stage_fill(L, lp, lane);
         const uint32_t v_ls = v_lp - L.base;                       // the literals' place in the stage (meaningful when staged)
-        // what lets a short step follow the one before without a look at anything else: the NEXT token's word, if that is a
-        // near short step and this token does not end in another ITXI_LAG bytes of output than it began (then the full stripes
-        // are written back first); 0 behind the batch's last token
-        const uint32_t v_nx = ITXI_NEXT(v_rt, lane);
-        const uint32_t v_rtn = ((int32_t)v_nx < 0 && ((v_gp + v_tot) ^ v_gp) < ITXI_LAG) ? v_nx : 0u;
-        // the two addresses a lane reads in a short step, less the token's own offsets: stage byte / ring byte of ITS place
-        for (uint32_t j = 0; j < nb; j++) {
-            uint32_t rt = ITXI_BCAST(v_rt, j);
-            if ((int32_t)rt < 0) {
-                // the short step: one byte per lane, literals from the stage, match bytes from the ring, one store each.
-                // EVERY lane stores: the lanes past the token's end put a stale byte where a later token will put the right
-                // one before anything reads or writes it back — what they overwrite in the ring lies a whole ring behind, out
-                // of any match's reach (ITXI_NEAR) and written back long ago. Short steps that follow one another run in a
-                // loop of their own (straight-line code: the scalar pipe is what this kernel is bound by) and leave the
-                // write-back of full stripes to its end — at most ITXI_LAG bytes later, well inside what the ring keeps.
-                // (Taking longer tokens this way too, 64 bytes a step, was measured slower: 15.4 ms instead of 13.0 per 24 k
-                // blocks — the literal runs of the long way round move a stripe per flush check.)
-                uint32_t jj = j;
-                do {
-                    const uint32_t g = ITXI_BCAST(v_gp, jj), d = ITXI_BCAST(cd, jj), ls = ITXI_BCAST(v_ls, jj);
-                    const uint32_t r = rt & 0xffffu;
-                    // one load whichever the source: the stage lies right behind the ring (checked above)
-                    const uint32_t a_lit = ITXI_RING + ls + lane, a_ring = (g + lane - d) & ITXI_MASK;
-                    const uint32_t from = a_ring ^ ((a_ring ^ a_lit) & (0u - (uint32_t)(lane < r)));
-                    ring8[(g + lane) & ITXI_MASK] = ring8[from];
-                    o.gp = g + ((rt >> 16) & 0xffu);
-                    rt = ITXI_BCAST(v_rtn, jj);                    // the next token's word if it may follow at once, else 0
-                    jj++;
-                } while ((int32_t)rt < 0);
-                j = jj - 1u;
+        // a token the steps may take: its literals staged, its bytes inside the bitmap's reach, its match inside the block
+        const bool v_ok = have && staged && v_tot != 0u && e_gp <= ITXI_BMAP && (is_run || cd <= gp0 - o.g0 + v_st + v_run);
+        const uint64_t fastmask = ITXI_BALLOT(v_ok);
+        if (fastmask != 0) {
+            for (uint32_t k = lane; k < (ITXI_BMAP + 64u) / 32u; k += ITXI_WAVE) bmap32[k] = 0;
+            if (v_ok) ITXI_LDS_OR(&bmap32[v_st >> 5], 1u << (v_st & 31u));
+        }
+        const uint32_t pk1 = v_run | (v_ls << 16);               // (staged: run and stage offset below 2^11)
+        uint32_t j = 0;
+        while (j < nb) {
+            const uint64_t rest = ~fastmask >> j;
+            uint32_t jn = rest ? j + (uint32_t)__builtin_ctzll(rest) : ITXI_WAVE;
+            if (jn > nb) jn = nb;
+            if (jn > j) {
+                // tokens [j, jn) as steps of a wave of bytes
+                const uint32_t seg_hi = ITXI_BCAST(e_gp, jn - 1u);
+                uint32_t base = ITXI_BCAST(v_st, j), n_before = j;                 // tokens of the batch that start before `base`
+                while (base < seg_hi) {
+                    const uint32_t p = base + lane;
+                    const bool valid = p < seg_hi;
+                    const uint32_t sbit = valid ? (bmap32[p >> 5] >> (p & 31u)) & 1u : 0u;
+                    const uint64_t M = ITXI_BALLOT(sbit != 0);
+                    const uint32_t t = n_before + ITXI_MBCNT(M, lane) + sbit - 1u;
+                    const uint32_t a_st = ITXI_LANE_READ(v_st, t), a1 = ITXI_LANE_READ(pk1, t), dist = ITXI_LANE_READ(cd, t);
+                    const uint32_t off = p - a_st, run = a1 & 0xffffu, ls = a1 >> 16;
+                    const bool is_lit = off < run;
+                    const uint32_t k = off - run;                                  // byte of the match
+                    uint32_t km = k;
+                    const bool wraps = valid && !is_lit && k >= dist;              // the match overlaps itself: its first `dist` bytes again
+                    if (ITXI_BALLOT(wraps) != 0) km = wraps ? k % dist : k;
+                    const int32_t src = (int32_t)(a_st + run + km) - (int32_t)dist;        // in the batch's coordinates; before the batch: negative
+                    const uint64_t cf = ITXI_BALLOT(valid && !is_lit && src >= (int32_t)base);
+                    uint32_t n_step = seg_hi - base < ITXI_WAVE ? seg_hi - base : ITXI_WAVE;
+                    if (cf != 0) {
+                        const uint32_t first = (uint32_t)__builtin_ctzll(cf);     // never lane 0: its source lies before its own place
+                        if (first < n_step) n_step = first;
+                    }
+                    const bool act = lane < n_step;
+                    const bool far = act && !is_lit && dist > ITXI_NEAR;
+                    const uint32_t a_lit = ITXI_RING + ls + off, a_ring = (gp0 + (uint32_t)src) & ITXI_MASK;
+                    uint32_t from = is_lit ? a_lit : a_ring;
+                    if (!act || far) from = 0;
+                    uint8_t byte = ring8[from];
+                    if (ITXI_BALLOT(far) != 0) {
+                        // further back than the ring reaches: those bytes left in whole stripes long ago (a statement of its own,
+                        // not a selected pointer: that would be a flat load)
+                        ITXI_FENCE();
+                        if (far) byte = ITXI_LOADB(o.g, gp0 + (uint32_t)src);
+                    }
+                    if (act) ring8[(gp0 + p) & ITXI_MASK] = byte;
+                    const uint64_t took = n_step >= 64u ? ~0ull : ((1ull << n_step) - 1ull);
+                    n_before += (uint32_t)__builtin_popcountll(M & took);
+                    base += n_step;
+                    o.gp = gp0 + base;
+                    if (o.gp - o.fl >= ITXI_LAG) itxi_flush_full(ring32, o, lane);
+                }
                 itxi_flush_full(ring32, o, lane);
-                continue;
+                j = jn;
+                if (j >= nb) break;
             }
-            if (rt & 0x40000000u) {
-                // the same with a match that reaches further back than the ring: those bytes left in whole stripes long ago
-                // (two statements, not one load through a selected pointer: that would be a flat load)
-                const uint32_t g = ITXI_BCAST(v_gp, j), d = ITXI_BCAST(cd, j), ls = ITXI_BCAST(v_ls, j);
-                const uint32_t r = rt & 0xffffu, tt = (rt >> 16) & 0xffu;
-                ITXI_FENCE();
-                if (lane < r) ring8[(g + lane) & ITXI_MASK] = ring8[ITXI_RING + ls + lane];
-                else if (lane < tt) ring8[(g + lane) & ITXI_MASK] = ITXI_LOADB(o.g, g + lane - d);
-                o.gp = g + tt;
-                itxi_flush_full(ring32, o, lane);
-                continue;
-            }
-            const uint32_t x = ITXI_BCAST(cx, j), dist = ITXI_BCAST(cd, j);
-            const uint32_t run = x & 0xffffu, len = x >> 16;
+            // token j the long way round
+            const uint32_t run = ITXI_BCAST(v_run, j), len = ITXI_BCAST(v_len, j), dist = ITXI_BCAST(cd, j);
             const uint32_t lpj = ITXI_BCAST(v_lp, j);              // == lp + the runs of the batch's tokens before this one
             // guards that hold for every token pass 1 lets through; they keep a damaged token array from leaving the block
-            if (lpj > n_lit || run > n_lit - lpj || run + len > o.gend - o.gp || len < 3u || len > 258u) return ITXI_E_OUTPUT;
+            if (lpj > n_lit || run > n_lit - lpj || run + len > o.gend - o.gp) return ITXI_E_OUTPUT;
             if (run) itxi_literals(ring32, o, L, lpj, run, lane);
-            if (dist == 0 || dist > o.gp - o.g0) return ITXI_E_DIST;
-            const uint32_t src0 = o.gp - dist;
-            if (dist <= ITXI_NEAR) {
-                if (dist >= 64u || dist >= len) {             // 64: the widest step any build takes
-                    // a step's sources were all written before the step (earlier steps or earlier tokens)
-                    for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
-                        const uint32_t k = k0 + lane;
-                        if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k) & ITXI_MASK];
+            if (len) {
+                if (dist == 0 || dist > o.gp - o.g0) return ITXI_E_DIST;
+                const uint32_t src0 = o.gp - dist;
+                if (dist <= ITXI_NEAR) {
+                    if (dist >= 64u || dist >= len) {             // 64: the widest step any build takes
+                        // a step's sources were all written before the step (earlier steps or earlier tokens)
+                        for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
+                            const uint32_t k = k0 + lane;
+                            if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k) & ITXI_MASK];
+                        }
+                    } else {
+                        // the match overlaps itself within a step: the output is the last `dist` bytes repeated
+                        for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
+                            const uint32_t k = k0 + lane;
+                            if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k % dist) & ITXI_MASK];
+                        }
                     }
                 } else {
-                    // the match overlaps itself within a step: the output is the last `dist` bytes repeated
+                    // further back than the ring reaches: those bytes left in whole stripes long ago (dist > 3 KiB > len)
+                    ITXI_FENCE();
                     for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
                         const uint32_t k = k0 + lane;
-                        if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ring8[(src0 + k % dist) & ITXI_MASK];
+                        if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ITXI_LOADB(o.g, src0 + k);
                     }
                 }
-            } else {
-                // further back than the ring reaches: those bytes left in whole stripes long ago (dist > 7 KiB > len)
-                ITXI_FENCE();
-                for (uint32_t k0 = 0; k0 < len; k0 += ITXI_WAVE) {
-                    const uint32_t k = k0 + lane;
-                    if (k < len) ring8[(o.gp + k) & ITXI_MASK] = ITXI_LOADB(o.g, src0 + k);
-                }
+                o.gp += len;
+                itxi_flush_full(ring32, o, lane);
             }
-            o.gp += len;
-            itxi_flush_full(ring32, o, lane);
+            j++;
         }
+        if (o.gp != gp0 + B) return ITXI_E_OUTPUT;
         lp += lit_total;
     }
     const uint32_t tail = n_lit - lp;

@@ -47,8 +47,12 @@ struct aln_reader {
     size_t clen;              /* a window into one of the two raw buffers below                                 */
     /* raw read-ahead (raw_next): a reader thread freads the next compressed chunk while this one is being inflated */
 #define N_RAW_DEVICE (ITX_BAMWIN_LANES + 2)
-    uint8_t *craw[N_RAW_DEVICE]; /* two for the host decoder; for the device's: one being read, one per push in flight, one just ended */
-    int n_raw;
+#define N_RAW_DEVICE_FILE 4
+    uint8_t *craw[N_RAW_DEVICE]; /* two for the host decoder. The device's, from a regular file: one being read, one being indexed, two whose
+                                  * pushes are copying (a buffer is free again once the pushes cut from it have COPIED their bytes: a block the
+                                  * device declines is read from the file once more); from a pipe: one per push in flight + 2, held until the push ends */
+    uint32_t raw_lanes[N_RAW_DEVICE];   /* per buffer: the lanes whose pushes read their compressed bytes from it (bit s = lane s) */
+    int n_raw, raw_cur;          /* raw_cur: the buffer cbuf points into */
     size_t io_got;
     int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
     size_t io_off, io_size;
@@ -83,6 +87,7 @@ struct aln_reader {
         struct blk *bl;        /* the chunk's blocks and where its compressed bytes lie, kept until its push has ended */
         size_t bl_cap, nb;
         const uint8_t *cbase;
+        size_t cabs;           /* file offset of cbase (regular files: SIZE_MAX otherwise) */
         int w, last;
         size_t trunc;          /* SIZE_MAX, or: the window ends this many fresh bytes in (the share's end boundary) */
     } dj[ITX_BAMWIN_LANES];
@@ -502,6 +507,7 @@ static size_t raw_next(aln_reader *r)
                 die("a share of %s was asked for, but it is not a regular file", "the alignment file");
             }
             r->io_abs_end = r->io_off;
+            if (r->dev && r->io_fd >= 0 && dev.push_copied) r->n_raw = N_RAW_DEVICE_FILE;
         }
         r->craw[0] = buf_alloc(RAW_HEAD + RAW_STEP + 64);          /* the others when the rotation first reaches them */
         pthread_mutex_init(&r->io_mu, NULL);
@@ -521,7 +527,16 @@ static size_t raw_next(aln_reader *r)
     r->cbuf = nb + RAW_HEAD - r->clen;
     r->clen += got;
     r->io_abs_end += got;
+    r->raw_cur = r->io_buf;
     r->io_buf = (r->io_buf + 1) % r->n_raw;
+    if (r->raw_lanes[r->io_buf]) {
+        /* the buffer the reader fills next: the pushes cut from it, n_raw - 1 chunks ago, have long copied their bytes */
+        pthread_mutex_unlock(&r->io_mu);
+        for (int sl = 0; sl < ITX_BAMWIN_LANES; sl++)
+            if (r->raw_lanes[r->io_buf] >> sl & 1u) DEV_CHK(dev.push_copied(dev.ctx, sl), "push_copied");
+        r->raw_lanes[r->io_buf] = 0;
+        pthread_mutex_lock(&r->io_mu);
+    }
     if (got == RAW_STEP) {
         if (!r->craw[r->io_buf]) {
             pthread_mutex_unlock(&r->io_mu);                       /* page-locking a buffer takes a while: not under the lock */
@@ -718,6 +733,8 @@ static void dev_begin(aln_reader *r)
     r->dstream_total += utot;
     j->nb = nb_use;
     j->cbase = r->cbuf;
+    j->cabs = r->io_fd >= 0 ? r->io_abs_end - r->clen : SIZE_MAX;
+    if (r->n_raw == N_RAW_DEVICE_FILE) r->raw_lanes[r->raw_cur] |= 1u << (k % ITX_BAMWIN_LANES);
     j->w = (int)(k % dev_nwin);
     j->last = damaged || share_done || (got == 0 && nb == 0);
     if (damaged && r->rg_on) r->rg_suspect = 1;
@@ -741,8 +758,15 @@ static void dev_end(aln_reader *r)
     int damaged = 0;
     for (size_t i = 0; i < j->nb; i++)
         if (r->dstatus[i]) {
-            uint8_t tmp[BGZF_MAX + 8];
-            if (inflate_block(j->cbase + j->bl[i].coff, j->bl[i].csize, tmp, j->bl[i].usize) == 0) {
+            uint8_t tmp[BGZF_MAX + 8], again[BGZF_MAX + 64];
+            const uint8_t *cb = j->cbase + j->bl[i].coff;
+            if (r->n_raw == N_RAW_DEVICE_FILE) {
+                /* the compressed bytes may have left their buffer by now: from the file once more */
+                cb = again;
+                if (j->bl[i].csize > sizeof again || pread(r->io_fd, again, j->bl[i].csize, (off_t)(j->cabs + j->bl[i].coff)) != (ssize_t)j->bl[i].csize)
+                    die("cannot read the BGZF block at offset %zu again", j->cabs + j->bl[i].coff);
+            }
+            if (inflate_block(cb, j->bl[i].csize, tmp, j->bl[i].usize) == 0) {
                 fprintf(stderr, "[iteres] note: BGZF block at chunk offset %zu declined by the device decoder (code %d), inflated by zlib\n", j->bl[i].coff,
                         r->dstatus[i]);
                 DEV_CHK(dev.patch(dev.ctx, j->w, j->bl[i].uoff, tmp, j->bl[i].usize), "patch");

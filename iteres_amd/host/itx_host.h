@@ -98,6 +98,7 @@ typedef struct aln_device_ops {
     int n_windows;
     size_t max_blocks, max_bytes;
     int (*xa_veto)(itx_inflater *, itx_xaveto *, size_t, size_t, uint64_t *, uint64_t *);      /* itx_bamwin_xa_veto */
+    int (*push_copied)(itx_inflater *, int);       /* itx_bamwin_push_copied: lane s's compressed bytes have left the caller's buffer */
 } aln_device_ops;
 void aln_use_device(const aln_device_ops *ops);
 #define ALN_DEVICE_CHUNK (128u << 20)       /* compressed bytes per chunk handed to the device decoder (ITX_BGZF_CHUNK overrides) */

@@ -9,7 +9,10 @@
 #define ITXI_UNI(x) (x)
 #define ITXI_BCAST(v, j) (v)
 #define ITXI_SCAN_ADD(v, lane) (v)
-#define ITXI_NEXT(v, lane) 0u
+#define ITXI_LANE_READ(v, j) (v)
+#define ITXI_BALLOT(p) ((uint64_t)((p) ? 1u : 0u))
+#define ITXI_MBCNT(m, lane) 0u
+#define ITXI_LDS_OR(ptr, v) ((void)(*(ptr) |= (v)))
 static inline uint32_t itxi_bitrev32(uint32_t x)
 {
     x = (x >> 16) | (x << 16);
@@ -37,17 +40,23 @@ extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, u
     static thread_local uint16_t offs[16], loffs[16], doffs[16];
     static thread_local uint8_t lsym8[288], dsym[32], lens[176];
     static thread_local uint32_t lhi[9];
-    static thread_local uint32_t mem32[(ITXI_RING + ITXI_LSTAGE) / 4];       // the literal stage right behind the ring (itxi_resolve's contract)
-    uint32_t *ring32 = mem32, *stage32 = mem32 + ITXI_RING / 4;
-    static thread_local std::vector<uint32_t> lit32(ITXI_MAX_BLOCK / 4 + 4);
-    uint8_t *lit = reinterpret_cast<uint8_t *>(lit32.data());
-    static thread_local std::vector<uint32_t> tok(2 * ITXI_MAX_TOK);
+    static thread_local uint32_t mem32[(ITXI_RING + ITXI_LSTAGE + ITXI_BMAP / 8 + 8) / 4];       // the literal stage right behind the ring (itxi_resolve's contract), then the bitmap
+    uint32_t *ring32 = mem32, *stage32 = mem32 + ITXI_RING / 4, *bmap32 = mem32 + (ITXI_RING + ITXI_LSTAGE) / 4;
+    // the block's scratch region: literals from its bottom, tokens from its top; guard words either side catch a writer that leaves it
+    static thread_local std::vector<uint32_t> region32(ITXI_REGION / 4 + 8);
+    region32[0] = region32[1] = region32[2] = region32[3] = 0xfeedc0deu;
+    for (int k = 0; k < 4; k++) region32[ITXI_REGION / 4 + 4 + k] = 0xfeedc0deu;
+    uint8_t *lit = reinterpret_cast<uint8_t *>(region32.data() + 4);
+    uint32_t *tok_top = region32.data() + 4 + ITXI_REGION / 4;
     if (usize > ITXI_MAX_BLOCK) return ITXI_E_OUTPUT;
     ItxiTab T{lsym8, lhi, dsym, offs, loffs, doffs, lens};
-    ItxiTokens K{lit, tok.data(), 0, 0};
+    ItxiTokens K{lit, tok_top, 0, 0};
     int rc = itxi_tokens(T, 0, comp_words, data_pos, data_end, usize, K);
     if (n_lit) *n_lit = K.n_lit;
     if (n_tok) *n_tok = K.n_tok;
+    for (int k = 0; k < 4; k++)
+        if (region32[k] != 0xfeedc0deu || region32[ITXI_REGION / 4 + 4 + k] != 0xfeedc0deu) return 100;           // pass 1 wrote outside its region
+    if (rc == ITXI_OK && (uint64_t)K.n_lit + 4u * (uint64_t)K.n_tok + 3u > ITXI_REGION) return 101;                   // literals and tokens met
     if (rc != ITXI_OK) return rc;
-    return itxi_resolve(ring32, stage32, lit, tok.data(), K.n_lit, K.n_tok, out, g0, usize, 0);
+    return itxi_resolve(ring32, stage32, bmap32, lit, tok_top, K.n_lit, K.n_tok, out, g0, usize, 0);
 }

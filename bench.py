@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 OURS = os.path.join(ROOT, "iteres_amd", "host", "iteres")
 REF = os.path.join(ROOT, "oracle", "_ref", "iteres")
+REF_O2 = os.path.join(ROOT, "oracle", "_ref", "o2", "iteres")
 MKBAM = os.path.join(ROOT, "tools", "mkbam")
 TEXT_OUTPUTS = ("out.iteres.subfamily.stat", "out.iteres.family.stat", "out.iteres.class.stat", "out.iteres.report", "out.iteres.wig",
                 "out.iteres.unique.wig")
@@ -66,7 +67,9 @@ def parse_args():
     ap.add_argument("--paired", type=int, default=0, help="1: fragments of two reads, isize ~ N(350, 60) (SURVEY.md 8(d)'s paired variant)")
     ap.add_argument("--pileup", type=int, default=0, help="K loci of the genome at ~2000x depth")
     ap.add_argument("--rows", type=int, default=5_500_000)
-    ap.add_argument("--cpu-reads", type=int, default=15_000_000, help="reads of the sample the reference binary is timed on (0 = skip)")
+    ap.add_argument("--cpu-reads", type=int, default=10_000_000, help="reads of the sample the reference binary is timed on (0 = skip)")
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="runs of the reference binary on the sample (the median is reported)")
+    ap.add_argument("--filter-steps", type=int, default=2, help="timed runs of `iteres filter -c <class>` on the same BAM (BASELINE configs[4]; 0 = skip)")
     ap.add_argument("--replay-steps", type=int, default=10, help="launches of the resident hot path behind `roofline` (0 = skip)")
     ap.add_argument("--replay-reads", type=int, default=0, help="records resident for the roofline replay (0 = --reads)")
     ap.add_argument("--threads", type=int, default=0, help="host threads of the command (0: min(16, cores))")
@@ -142,6 +145,19 @@ def ensure_inputs(a, threads):
         subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.cpu_reads), os.path.join(wd, "sample.bam"), str(a.seq_len), "7"] + mkopts, env=env)
     info = {"table_s": round(t1 - t0, 1), "bam_s": round(time.time() - t1, 1), "bam_bytes": os.path.getsize(os.path.join(wd, "reads.bam")),
             "n_rep": len(tb.names), "n_fam": len(tb.fams), "n_cla": len(tb.clas)}
+    # what the decoder has to chew: literals / matches per BGZF block, bytes per read (a sample of blocks spread over the file,
+    # counted by pass 1 of the product's decoder built for the host and compared with zlib)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bam_content
+        info["content"] = bam_content.content_stats(os.path.join(wd, "reads.bam"), 200)
+    except Exception as e:                                                    # never fatal: it is a description
+        info["content"] = {"error": str(e)[:200]}
+    # the filter leg (configs[4]) takes the biggest class: how many of the rows it holds
+    import numpy as np
+    per_cla = np.bincount(np.asarray(tb.cla_of_row), minlength=len(tb.clas))
+    k = int(per_cla.argmax())
+    info["filter_class"] = {"name": tb.clas[k], "rows": int(per_cla[k]), "fraction_of_rows": round(float(per_cla[k]) / max(len(tb.cla_of_row), 1), 4)}
     json.dump(info, open(done, "w"))
     return wd, info
 
@@ -262,6 +278,8 @@ def resident_roofline(a, n_records, steps, rank, with_check):
         except Exception:
             traffic = None
     out["traffic"] = traffic
+    out["traffic_source"] = ("not measured in this run: bytes per record from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in passes of their own "
+                             "over this same command, tools/profile_bench.sh; 2 x FETCH_SIZE + WRITE_SIZE per the gfx950 correction) x the records of a launch")
     # attainable bandwidth on THIS card: a plain 1 GiB device copy, best of 5
     src = torch.empty(1 << 28, dtype=torch.int32, device=dev).fill_(1)
     dst = torch.empty_like(src)
@@ -288,12 +306,58 @@ def resident_roofline(a, n_records, steps, rank, with_check):
         ot.add_rows(tb.chrom, tb.start, tb.end, tb.cons_start, tb.cons_end, tb.rep_name, tb.fam_of_row, tb.cla_of_row)
         flag16 = np.where(h["flag5"] & 8, 16, 0).astype(np.uint16)
         want = ot.run({}, list(range(len(chroms))), h["tid"], h["pos"], h["tmpend"], h["mapq"], flag16, want_hits=False)
-        ot.close()
         e.reset()
         e.submit_device(ptrs, m, stream=stream)
         got = e.finish()
         checks["resident_sample_matches_oracle"] = bool(all(np.array_equal(got[k], want[k]) for k in ("cnt", "rep_cnt", "fam_cnt", "cla_cnt", "cov", "cov_uniq")))
+        # "a fair multi-core CPU number for our restatement": the oracle (the hot path only: decoded records in,
+        # counters and coverage out) on every core of this process's CPU share — contiguous shards, private accumulators, the
+        # read-only table shared; something the reference's process-global state cannot do
+        nthr = max(1, min(len(os.sched_getaffinity(0)), 16))
+        from concurrent.futures import ThreadPoolExecutor
+        mm = min(n_records, m * 4)
+        hh = {k: v[:mm].cpu().numpy() for k, v in d.items()}
+        fl_all = np.where(hh["flag5"] & 8, 16, 0).astype(np.uint16)
+        cuts = [(mm * t // nthr, mm * (t + 1) // nthr) for t in range(nthr)]
+
+        def one(b):
+            lo, hi = b
+            return ot.run({}, list(range(len(chroms))), hh["tid"][lo:hi], hh["pos"][lo:hi], hh["tmpend"][lo:hi], hh["mapq"][lo:hi], fl_all[lo:hi], want_hits=False)["cnt"]
+        t2 = time.perf_counter()
+        one((0, m))
+        st_s = time.perf_counter() - t2
+        t3 = time.perf_counter()
+        with ThreadPoolExecutor(nthr) as ex:
+            parts = list(ex.map(one, cuts))
+        mt_s = time.perf_counter() - t3
+        checks["cpu_mt_counts_all_records"] = bool(int(sum(int(c[0]) for c in parts)) == mm)
+        out["cpu_baseline_mt"] = {"value": round(mm / mt_s / 1e6, 3), "unit": "M alignments/s", "cores": nthr, "kind": "port",
+                                  "sample": (f"oracle/liboracle.so (our single-threaded C restatement of generic.c:745-1036) on the first {mm} DECODED records of the resident set in {nthr} "
+                                             f"contiguous shards, one thread each, private accumulators, merge not timed ({mt_s:.1f} s); hot path only — no BAM decode, no files"),
+                                  "one_thread_M_alignments_per_s": round(m / st_s / 1e6, 3)}
+        ot.close()
     e.close()
+    # configs[4]: the same kernel in filter mode (k_stream<ATOMIC_LOCUS>: derive + classify + one atomic per run of equal rows)
+    if getattr(a, "filter_steps", 0) > 0:
+        ef = eng.Engine(table, {"filter_mode": True}, batch_capacity=n_records)
+        ef.set_tidmap(list(range(len(chroms))))
+        ef.submit_device(ptrs, n_records, stream=stream)
+        ef.sync()
+        ef.reset()
+        torch.cuda.synchronize()
+        for _ in range(steps):
+            ef.submit_device(ptrs, n_records, stream=stream)
+        ef.sync()
+        sf = ef.stats()
+        rf = ef.finish()
+        fms = sf["stage_ms"][0] / max(sf["submits"], 1)
+        out["filter_kernel"] = {"kernel": "k_stream<ATOMIC_LOCUS> (derive + classify + per-locus count)", "avg_launch_ms": round(fms, 4), "launches": int(sf["submits"]),
+                                "records_per_launch": n_records, "algorithmic_bytes_per_launch": int(survey_bytes),
+                                "achieved": round(survey_bytes / (fms * 1e-3) / 1e9, 2) if fms > 0 else 0.0, "unit": "GB/s",
+                                "frac": round(survey_bytes / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if fms > 0 else 0.0,
+                                "bytes_accounting": "SURVEY.md 8(d) K1 as for stat: 18 B/read (14 in + the 4-byte per-locus count) + 28 B x table rows + index; full table, every class"}
+        checks["filter_locus_sum_equals_cnt9"] = bool(int(rf["locus_cnt"].astype(np.uint64).sum()) == int(rf["cnt"][9]))
+        ef.close()
     table.close()
     return out, checks
 
@@ -447,11 +511,16 @@ def main():
             "value": round(total_reads / elapsed / 1e6, 3), "unit": "M alignments/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[2]: `iteres stat -w` end to end on a {a.reads}-read coordinate-sorted synthetic hg38 BAM "
-                                    f"({a.seq_len} bases + qualities per record, {info['bam_bytes'] / 1e9:.1f} GB BGZF) vs {a.rows}-row rmsk, reference defaults, "
+                                    f"({a.seq_len} bases + qualities per record, content={a.content}, cigar={a.cigar}{', paired' if a.paired else ''}, {info['bam_bytes'] / 1e9:.1f} GB BGZF) vs {a.rows}-row rmsk, reference defaults, "
                                     "per-base coverage wigs on; one step = one whole run of the command")
                        if world == 1 else
                        (f"BASELINE configs[3], weak: `iteres stat -w` on a list of {world} such {a.reads}-read BAMs over {world} GPUs (one process per GPU, "
                         "shares of the compressed bytes, one RCCL sum-reduce of the partial onto rank 0, rank 0 writes the files)"),
+                       "content": dict({"mode": a.content, "cigar": a.cigar, "paired": int(a.paired), "pileup_loci": int(a.pileup),
+                                         "what": {"hiseq": "independent bases per nibble, 40-value HiSeq-like qualities, Illumina-style names: literal-heavy DEFLATE streams — the content `value` is timed on",
+                                                  "novaseq": "independent bases, 4-bin run-structured qualities",
+                                                  "legacy": "round 2's file: one base per byte pair and a period-32 quality pattern — 97 % of the bytes come out of LZ77 matches (a best case)"}[a.content]},
+                                        **(info.get("content") or {})),
                        "reads_per_step": a.reads * world, "seq_len": a.seq_len, "bam_bytes": info["bam_bytes"], "rmsk_rows": a.rows,
                        "host_threads_per_rank": threads, "host_cores_visible": os.cpu_count(),
                        "timed_region": "K runs of the whole command (process start to exit), files in the page cache"},
@@ -473,35 +542,82 @@ def main():
     if rank == 0 and world == 1 and a.cpu_reads > 0 and os.path.exists(REF):
         sample = os.path.join(wd, "sample.bam")
         renv = dict(os.environ)
-        wall_r, rc_r, err_r, seen_r = run_timed(REF, base_args(wd) + [sample], os.path.join(wd, "ref_run"), renv, (SCAN_BEGIN, SCAN_END))
+        runs = []
+        for k in range(max(1, a.cpu_repeats)):
+            wall_r, rc_r, err_r, seen_r = run_timed(REF, base_args(wd) + [sample], os.path.join(wd, "ref_run"), renv, (SCAN_BEGIN, SCAN_END))
+            scan_k = seen_r.get(SCAN_END, 0) - seen_r.get(SCAN_BEGIN, 0) if SCAN_BEGIN in seen_r and SCAN_END in seen_r else None
+            runs.append((wall_r, scan_k, rc_r))
+            log(f"reference run {k + 1}/{a.cpu_repeats}: {wall_r:.1f} s (rc {rc_r})")
+        runs.sort(key=lambda x: x[0])
+        wall_r, scan_r, rc_r = runs[len(runs) // 2]                            # the median run
         wall_o, rc_o, err_o, _ = run_timed(OURS, base_args(wd) + [sample], os.path.join(wd, "ours_sample"), env)
         same = {fn: (os.path.exists(os.path.join(wd, "ours_sample", fn)) and os.path.exists(os.path.join(wd, "ref_run", fn))
                      and filecmp.cmp(os.path.join(wd, "ref_run", fn), os.path.join(wd, "ours_sample", fn), shallow=False)) for fn in TEXT_OUTPUTS}
-        scan_r = seen_r.get(SCAN_END, 0) - seen_r.get(SCAN_BEGIN, 0) if SCAN_BEGIN in seen_r and SCAN_END in seen_r else None
         fixed_r = wall_r - scan_r if scan_r else None
         full_est = (fixed_r + a.reads / (a.cpu_reads / scan_r)) if scan_r else None
         out["cpu_baseline"] = {
             "value": round(a.cpu_reads / wall_r / 1e6, 4), "unit": "M alignments/s", "cores": 1, "kind": "reference",
             "sample": (f"oracle/_ref/iteres stat -w (the reference's own sources, -O as its makefile, single-threaded like the reference) on a {a.cpu_reads}-read BAM "
-                       f"from the same generator / table ({wall_r:.1f} s whole command, rc {rc_r})"),
+                       f"from the same generator / table; median of {len(runs)} runs ({wall_r:.1f} s whole command, rc {rc_r})"),
+            "runs_wall_s": [round(r[0], 2) for r in runs],
             "scan_only_M_alignments_per_s": round(a.cpu_reads / scan_r / 1e6, 4) if scan_r else None,
             "fixed_s": round(fixed_r, 2) if fixed_r else None,
-            "extrapolated_full_size": {"what": f"fixed_s + {a.reads} reads / scan rate (linear, BASELINE.md 3.3)", "seconds": round(full_est, 1) if full_est else None,
+            "extrapolated_full_size": {"what": f"fixed_s + {a.reads} reads / scan rate (linear, BASELINE.md 3.3) — arithmetic, not a measurement",
+                                       "seconds": round(full_est, 1) if full_est else None,
                                        "M_alignments_per_s": round(a.reads / full_est / 1e6, 4) if full_est else None},
             "drop_in_same_sample_wall_s": round(wall_o, 2),
+            "host_cores_visible": os.cpu_count(),
         }
+        # the same sources at -O2 (reported separately), one run
+        if os.path.exists(REF_O2):
+            wall_2, rc_2, _, seen_2 = run_timed(REF_O2, base_args(wd) + [sample], os.path.join(wd, "ref_run_o2"), renv, (SCAN_BEGIN, SCAN_END))
+            scan_2 = seen_2.get(SCAN_END, 0) - seen_2.get(SCAN_BEGIN, 0) if SCAN_BEGIN in seen_2 and SCAN_END in seen_2 else None
+            out["cpu_baseline"]["O2_build"] = {"what": "oracle/_ref/o2/iteres: the same sources with -O2 instead of the makefile's -O, one run on the same sample",
+                                               "wall_s": round(wall_2, 2), "M_alignments_per_s": round(a.cpu_reads / wall_2 / 1e6, 4), "rc": rc_2,
+                                               "scan_only_M_alignments_per_s": round(a.cpu_reads / scan_2 / 1e6, 4) if scan_2 else None}
         out["files_identical"] = same
         out["checks"]["sample_outputs_identical_to_reference"] = bool(rc_r == 0 and rc_o == 0 and all(same.values()))
         if full_est:
-            out["speedup_vs_cpu_reference"] = {"whole_command_at_full_size_extrapolated": round(out["value"] / (a.reads / full_est / 1e6), 1),
-                                               "same_sample_measured": round(wall_r / wall_o, 1)}
+            out["speedup_vs_cpu_reference"] = {"same_sample_measured": round(wall_r / wall_o, 1),
+                                               "whole_command_at_full_size_extrapolated": round(out["value"] / (a.reads / full_est / 1e6), 1),
+                                               "note": "only the same-sample figure is a measurement of both programs; the other divides by the extrapolation above"}
     elif rank == 0 and world == 1:
         out["cpu_baseline"] = None
+
+    # ---------------------------------------------------------------- configs[4]: `iteres filter -c <class>` on the same BAM (rank 0, N = 1)
+    if rank == 0 and world == 1 and a.filter_steps > 0 and info.get("filter_class"):
+        fc = info["filter_class"]
+        fargs = lambda aln: ["filter", "-c", fc["name"], "-o", "out", os.path.join(wd, "chrom.sizes"), os.path.join(wd, "rep.sizes"), os.path.join(wd, "rmsk.txt"), aln]
+        fdir = os.path.join(wd, "filter_run")
+        walls, ferr = [], ""
+        for k in range(a.filter_steps + 1):                                   # the first run is the warm-up
+            w, rc_f, ferr, _ = run_timed(OURS, fargs(bam), fdir, env)
+            if rc_f != 0:
+                raise RuntimeError(f"iteres filter failed ({rc_f}): {ferr[-800:]}")
+            if k:
+                walls.append(round(w, 3))
+        leg = {"what": f"`iteres filter -c {fc['name']}` (the biggest class: {fc['rows']} rows = {fc['fraction_of_rows']:.1%} of the table) end to end on the same {a.reads}-read BAM",
+               "wall_s": walls, "M_alignments_per_s": round(a.reads / (sum(walls) / len(walls)) / 1e6, 2),
+               "phases_last_run": [ln for ln in ferr.replace("\r", "\n").split("\n") if ln.startswith("[itx timing]")]}
+        if a.cpu_reads > 0 and os.path.exists(REF):
+            sample = os.path.join(wd, "sample.bam")
+            w_r, rc_r, _, _ = run_timed(REF, fargs(sample), os.path.join(wd, "filter_ref"), dict(os.environ))
+            w_o, rc_o, _, _ = run_timed(OURS, fargs(sample), os.path.join(wd, "filter_ours_sample"), env)
+            names = [f"out_{fc['name']}.iteres.loci", f"out_{fc['name']}.iteres.reportloci"]
+            fsame = {fn: (os.path.exists(os.path.join(wd, "filter_ref", fn)) and os.path.exists(os.path.join(wd, "filter_ours_sample", fn))
+                          and filecmp.cmp(os.path.join(wd, "filter_ref", fn), os.path.join(wd, "filter_ours_sample", fn), shallow=False)) for fn in names}
+            leg["reference_on_sample"] = {"wall_s": round(w_r, 2), "M_alignments_per_s": round(a.cpu_reads / w_r / 1e6, 4), "rc": rc_r,
+                                          "drop_in_same_sample_wall_s": round(w_o, 2), "files_identical": fsame}
+            out["checks"]["filter_sample_outputs_identical_to_reference"] = bool(rc_r == 0 and rc_o == 0 and all(fsame.values()))
+        out["filter_leg"] = leg
 
     # ---------------------------------------------------------------- roofline of the overlap kernel, records resident in HBM (rank 0)
     if rank == 0 and a.replay_steps > 0:
         n_res = a.replay_reads or a.reads
         roof, rchecks = resident_roofline(a, n_res, a.replay_steps, rank, with_check=(world == 1 and not a.no_replay_check))
+        for k in ("cpu_baseline_mt", "filter_kernel"):                        # measured inside the replay, reported beside it
+            if k in roof:
+                (out["filter_leg"] if k == "filter_kernel" and "filter_leg" in out else out)[k] = roof.pop(k)
         out["roofline"] = roof
         out["checks"].update(rchecks)
     if rank == 0:

@@ -101,7 +101,13 @@ typedef struct aln_device_ops {
     int (*push_copied)(itx_inflater *, int);       /* itx_bamwin_push_copied: lane s's compressed bytes have left the caller's buffer */
 } aln_device_ops;
 void aln_use_device(const aln_device_ops *ops);
-#define ALN_DEVICE_CHUNK (128u << 20)       /* compressed bytes per chunk handed to the device decoder (ITX_BGZF_CHUNK overrides) */
+size_t aln_raw_step(size_t left);           /* bytes per read step of a regular file with `left` bytes to go (after aln_use_device) */
+/* compressed bytes per chunk handed to the device decoder (ITX_BGZF_CHUNK overrides). Pass 1 of the decoder is a lane per
+ * block and bound by the latency of one block's symbol chain (~29 ms for a block of literal-heavy content, whatever the number
+ * of blocks, until every SIMD holds a wave: 65 k blocks): its throughput is the blocks in flight. Blocks of real BAM content
+ * take ~33 KB compressed, so 384 MB = 12 k blocks per push, four pushes in flight = 48 k blocks (round 2: 128 MB, written for
+ * blocks of 15 KB). Measured, 200 M reads of 40-value-quality content: record loop 1.35 s -> 0.64 s. */
+#define ALN_DEVICE_CHUNK (384u << 20)
 /* Device decoder only. aln_device_window: 1 when the next records can be taken as DEVICE arrays — the reader stands at
  * the start of a decoded window (decoding the next one if need be); *flags: bit 0 some record of the window is paired,
  * bit 1 some record carries an XA tag; *tid_seen[n_targets]: references with a mapped record in the window. 0: host
@@ -208,6 +214,13 @@ char *slurp_text(const char *path, size_t *len);
  * rank 0 writes the files, the others leave. */
 void multi_early(int argc, char **argv);            /* from main(): picks up a launcher's rank, quiets ranks > 0 */
 void multi_begin(int splittable, const char *aln_arg, int multi_file);   /* after the options are known, before the first GPU call: starts the other ranks */
+/* shares.c: this rank's share of every alignment file (compressed byte ranges; aln_open_range turns them into record boundaries) */
+typedef struct {
+    size_t lo, hi;             /* hi = SIZE_MAX: to the end of the file; lo == hi: nothing of this file */
+} share_t;
+/* sh[fi] for `rank` of `world`; returns 0 when the job cannot be shared (then rank 0 has everything, the others nothing):
+ * not splittable, a file that is no regular file, or less than min_share compressed bytes per rank */
+int plan_shares(char **files, int n_files, int splittable, int rank, int world, size_t min_share, share_t *sh);
 size_t multi_min_share(void);                       /* compressed bytes below which a share is not worth a rank (ITX_SPLIT_MIN) */
 void multi_finish(void);                            /* rank 0, before it returns: the ranks it started have all left */
 int multi_rank(void);

@@ -76,43 +76,7 @@ static void use_device_reader(void)
     aln_use_device(&ops);
 }
 
-/* ---- the shares of a multi-GPU job: the compressed bytes of all alignment files, laid end to end, are cut into
- * multi_world() equal ranges; a rank takes, of every file, what falls into its range (aln_open_range turns the byte
- * offsets into record boundaries). One rank: everything. */
-typedef struct {
-    size_t lo, hi;             /* hi = SIZE_MAX: to the end of the file; lo == hi: nothing of this file */
-} share_t;
-
-/* sh[fi] for this rank; returns 0 when the job cannot be shared (then rank 0 has everything, the others nothing) */
-static int plan_shares(char **files, int n_files, int splittable, int rank, int world, share_t *sh)
-{
-    for (int i = 0; i < n_files; i++) {
-        sh[i].lo = 0;
-        sh[i].hi = rank == 0 ? SIZE_MAX : 0;
-    }
-    if (world <= 1) return 1;
-    if (!splittable) return 0;
-    size_t size[100], total = 0;
-    for (int i = 0; i < n_files; i++) {
-        struct stat sb;
-        if (stat(files[i], &sb) != 0 || !S_ISREG(sb.st_mode)) return 0;       /* a pipe, or a file that is not there (reported where the reference does) */
-        size[i] = (size_t)sb.st_size;
-        total += size[i];
-    }
-    if (total / (size_t)world < multi_min_share()) return 0;
-    const size_t g0 = (size_t)((__uint128_t)total * (unsigned)rank / (unsigned)world), g1 = (size_t)((__uint128_t)total * ((unsigned)rank + 1) / (unsigned)world);
-    size_t base = 0;
-    for (int i = 0; i < n_files; i++) {
-        const size_t a = g0 > base ? g0 - base : 0, b = g1 > base ? g1 - base : 0;
-        sh[i].lo = a < size[i] ? a : size[i];
-        sh[i].hi = b < size[i] ? b : SIZE_MAX;
-        if (sh[i].hi != SIZE_MAX && sh[i].hi <= sh[i].lo) sh[i].lo = sh[i].hi = 0;
-        if (sh[i].lo >= size[i]) sh[i].lo = sh[i].hi = 0;
-        base += size[i];
-    }
-    return 1;
-}
-
+/* the shares of a multi-GPU job: shares.c (share_t, plan_shares) */
 static int warm_splittable;
 static size_t warm_input_bytes;               /* size of all alignment files together (0: unknown) */
 
@@ -201,7 +165,11 @@ static void *warm_main(void *arg)
         const char *ce = getenv("ITX_BGZF_CHUNK");
         const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
         size_t want[POOL_N];
-        for (int i = 0; i < POOL_N; i++) want[i] = chunk + (1u << 17);
+        use_device_reader();                                             /* (aln_raw_step asks which decoder is in use) */
+        /* what the reader will ask for: a step's bytes plus room for a carried-over block; a small input gets small buffers */
+        const size_t mine_bytes = warm_input_bytes ? warm_input_bytes / (size_t)(multi_world() > 0 ? multi_world() : 1) : 0;
+        const size_t step = mine_bytes && !ce ? aln_raw_step(mine_bytes + mine_bytes / 64) : chunk;
+        for (int i = 0; i < POOL_N; i++) want[i] = step + (1u << 17);
         /* the first two now; the third is locked by the producer thread when it first needs it, beside the device's work */
         for (int i = 0; i < 2 && i < POOL_N; i++) {
             pool[i].p = itx_pinned_alloc(want[i]);
@@ -222,8 +190,17 @@ static void *warm_main(void *arg)
             const size_t nchunks = mine / chunk + 3;
             if (nchunks < ITX_BAMWIN_WINDOWS) g_dev_windows = (int)nchunks;          /* in: the most this input can use */
         }
+        /* The ring the pushes rotate through: the pushes in flight plus as many windows again for the consumer. A deeper ring
+         * (round 2: up to 48 windows, 50 GB of HBM for a 23 GB file) only let the decoder run ahead while the table was still
+         * being built, and paid for it in device allocation time — seconds on a box whose memory the driver had yet to clear;
+         * measured on 200 M reads: 8 windows 2.27 - 2.35 s per run, 48 windows 2.37 - 2.58 s. ITX_RESERVE_WINDOWS overrides. */
+        {
+            const char *we = getenv("ITX_RESERVE_WINDOWS");
+            const int ring = we && atol(we) >= 2 && atol(we) <= ITX_BAMWIN_WINDOWS ? (int)atol(we) : 2 * ITX_BAMWIN_LANES;
+            if (g_dev_windows < 1 || g_dev_windows > ring) g_dev_windows = ring;
+        }
         const size_t max_bytes = max_blocks * 65280u < ((size_t)1 << 30) ? max_blocks * 65280u : (size_t)1 << 30;
-        if (!getenv("ITX_NO_RESERVE") && itx_inflater_reserve(g_inflater, chunk + (1u << 17), max_blocks, max_bytes, &g_dev_windows) == ITX_OK) {
+        if (!getenv("ITX_NO_RESERVE") && itx_inflater_reserve(g_inflater, step + (1u << 17), max_blocks, max_bytes, &g_dev_windows) == ITX_OK) {
             g_dev_max_blocks = max_blocks;
             g_dev_max_bytes = max_bytes;
         } else {
@@ -240,7 +217,7 @@ static void *warm_main(void *arg)
         /* this rank's share of the FIRST file when the list has one file (the common case); longer lists are opened by the loop */
         if (multi_world() <= 1) {
             warm_reader = aln_open(warm_first, 0);
-        } else if (warm_single && plan_shares(one, 1, warm_splittable, multi_rank(), multi_world(), &sh0) && sh0.lo != sh0.hi) {
+        } else if (warm_single && plan_shares(one, 1, warm_splittable, multi_rank(), multi_world(), multi_min_share(), &sh0) && sh0.lo != sh0.hi) {
             warm_reader = aln_open_range(warm_first, sh0.lo, sh0.hi);
             warm_lo = sh0.lo;
             warm_hi = sh0.hi;
@@ -449,7 +426,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     /* this rank's share of every file (one rank: all of it) */
     share_t share[100];
     const int world = multi_world(), rank = multi_rank();
-    int shared = plan_shares(files, n_files, warm_splittable && !getenv("ITX_HOST_INFLATE"), rank, world, share) && world > 1;
+    int shared = plan_shares(files, n_files, warm_splittable && !getenv("ITX_HOST_INFLATE"), rank, world, multi_min_share(), share) && world > 1;
     unsigned long long boundary_missed = 0;
     /* the helper thread (HIP start-up, device decoder, first file opened and decoding ahead) has had the rmsk parse and the
      * table build to finish */
@@ -786,7 +763,12 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             fprintf(stderr, "[itx timing] exchange (%s): export %.3f s, communicator %.3f s, reduce of %.1f MB per rank (waits for the slowest rank) %.3f s\n",
                     comm_mode == ITX_COMM_FILE ? "files" : "RCCL", tc - tx, ty - tc, (double)(n64 * 8 + n32 * 4) / 1e6, now_s() - ty);
         itx_comm_destroy(comm);
-        if (rank == 0 && world > 1) comm_markers_remove();          /* every rank has read them: its partial is here */
+        if (rank == 0 && world > 1) {
+            comm_markers_remove();                                   /* every rank has read them: its partial is here */
+            /* RCCL was given up for the files: the communicator id this rank may have written for it (its thread still sits in
+             * ncclCommInitRank, waiting for a rank that will not come) goes too */
+            if (comm_mode == ITX_COMM_FILE && multi_comm_mode() == ITX_COMM_RCCL) unlink(multi_comm_id());
+        }
         if (rank > 0) {                                              /* handed over: rank 0 writes the files */
             fflush(NULL);
             _exit(0);

@@ -269,3 +269,75 @@ def test_a_later_rank_without_rccl_takes_every_rank_to_the_files(exe, big_case, 
     assert "exchange (files)" in errs[0] and "cannot load librccl" in errs[1], errs
     _same_dir(ref_dir, str(tmp_path / "rank0"))
     assert not [f for f in os.listdir(tmp_path) if f.startswith("job.id")], os.listdir(tmp_path)
+
+
+# ---- for the first box with more than one GPU: two RCCL ranks really meet (skipped where one device is visible) ---------------
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()                                       # (counting devices does not initialise the GPU)
+
+
+need2 = pytest.mark.skipif(_n_devices() < 2, reason="needs at least two visible GPUs (two RCCL ranks cannot share a device)")
+
+
+@need2
+@pytest.mark.parametrize("head", [["stat", "-w"], ["filter", "-n", "Rep3"]])
+@pytest.mark.parametrize("gpus", ["2", "all"])
+def test_rccl_exchange_between_real_ranks(head, gpus, exe, big_case, tmp_path):
+    """ITX_GPUS=2 / all on a multi-GPU box: the command starts its ranks itself, one per device, every rank makes its RCCL
+    communicator beside the scan, the partials meet in ncclReduce on rank 0 — asserted from the timing line — and the files are
+    the one-rank run's, byte for byte (stat over a list of files as well: shares that start and end inside different files)."""
+    d = big_case
+    lst = ",".join(str(d / n) for n in ("a.bam", "b.bam", "c.bam"))
+    for aln, what in ((str(d / "a.bam"), "one"), (lst, "list")):
+        if head[0] == "filter" and what == "list":
+            continue
+        ref_dir, out = str(tmp_path / f"plain_{what}"), str(tmp_path / f"rccl_{what}")
+        _run(exe, head, d, aln, ref_dir, dict(os.environ, ITX_GPUS="1"))
+        env = dict(os.environ, ITX_GPUS=gpus, ITX_SPLIT_MIN="1", ITX_TIMING="1", ITX_COMM_TIMEOUT="120")
+        env.pop("ITX_GPU_MAP", None)
+        pr = _run(exe, head, d, aln, out, env)
+        assert "exchange (RCCL)" in pr.stderr and "share boundary" not in pr.stderr, pr.stderr[-2000:]
+        _same_dir(ref_dir, out)
+
+
+@need2
+def test_rccl_exchange_reproduces_reference_files(exe, tmp_path):
+    """... and against the reference's own files: BASELINE configs[0] (the 100 k-read chr22 case) as a job of two RCCL ranks."""
+    case, run_name = next((c, r) for c, r in BAM_RUNS if c.startswith("cfg1") and gc.manifest_run(c, r)["cmd"] == "stat"
+                          and not any(o in gc.manifest_run(c, r)["opts"] for o in ("-R", "-B", "-V")))
+    run = gc.manifest_run(case, run_name)
+    src = os.path.join(gc.GOLDEN, case, "in")
+    paths = [refio.materialise(src, n, str(tmp_path)) for n in ["chrom.sizes", "rep.sizes", "rmsk.txt", run["aln"]]]
+    work = tmp_path / "out"
+    work.mkdir()
+    env = dict(os.environ, ITX_GPUS="2", ITX_SPLIT_MIN="1", ITX_TIMING="1", ITX_COMM_TIMEOUT="120", ITX_BGZF_CHUNK="400000")
+    env.pop("ITX_GPU_MAP", None)
+    pr = subprocess.run([exe, run["cmd"]] + run["opts"] + ["-o", run["prefix"]] + paths, cwd=work, capture_output=True, text=True, timeout=600, env=env)
+    assert pr.returncode == run["rc"], pr.stderr[-2000:]
+    assert "exchange (RCCL)" in pr.stderr, pr.stderr[-2000:]
+    for fn in run["files"]:
+        assert (work / fn).read_bytes() == refio.read_bytes(os.path.join(gc.GOLDEN, case, run_name, fn)), fn
+
+
+@need2
+def test_two_launcher_ranks_meet_in_rccl(exe, big_case, tmp_path):
+    """The way bench.py --gpus N runs the command: ranks started by somebody else (ITX_RANK / ITX_WORLD / ITX_DEVICE), each on its
+    own device, RCCL asked for: rank 0 writes the one-rank run's files, rank 1 is silent."""
+    d = big_case
+    aln = str(d / "a.bam")
+    ref_dir = str(tmp_path / "plain")
+    _run(exe, ["stat", "-w"], d, aln, ref_dir, dict(os.environ, ITX_GPUS="1"))
+    args = [exe, "stat", "-w", "-o", "out", str(d / "chrom.sizes"), str(d / "rep.sizes"), str(d / "rmsk.txt"), aln]
+    procs = []
+    for r in range(2):
+        out = tmp_path / f"rank{r}"
+        out.mkdir()
+        env = dict(os.environ, ITX_RANK=str(r), ITX_WORLD="2", ITX_DEVICE=str(r), ITX_COMM_ID=str(tmp_path / "job.id"), ITX_EXCHANGE="rccl",
+                   ITX_SPLIT_MIN="1", ITX_TIMING="1", ITX_COMM_TIMEOUT="120")
+        procs.append(subprocess.Popen(args, cwd=out, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    errs = [p.communicate(timeout=300)[1] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], errs
+    assert "exchange (RCCL)" in errs[0], errs[0][-1500:]
+    _same_dir(ref_dir, str(tmp_path / "rank0"))
+    assert os.listdir(str(tmp_path / "rank1")) == []

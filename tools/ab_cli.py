@@ -43,7 +43,7 @@ def main():
             assert rc == 0, err[-800:]
             walls[name].append(round(wall, 3))
             scans[name].append(round(seen.get(bench.SCAN_END, 0) - seen.get(bench.SCAN_BEGIN, 0), 3))
-            notes[name] = [ln[13:] for ln in err.split("\n") if "device decoder:" in ln or "BAM decode so far" in ln or "table build" in ln]
+            notes[name] = [ln[13:] for ln in err.replace("\r", "\n").split("\n") if ln.startswith("[itx timing]")]
     same = {}
     for name, _ in settings[1:]:
         same[name] = all(open(os.path.join(wd, "ab_base", fn), "rb").read() == open(os.path.join(wd, "ab_" + name, fn), "rb").read() for fn in bench.TEXT_OUTPUTS)

@@ -350,7 +350,7 @@ def resident_roofline(a, n_records, steps, rank, with_check):
         ef.sync()
         sf = ef.stats()
         rf = ef.finish()
-        fms = sf["stage_ms"][0] / max(sf["submits"], 1)
+        fms = sf["kernel_ms"] / max(sf["submits"], 1)                       # filter mode: one kernel per submit, timed by the engine's HIP events around it
         out["filter_kernel"] = {"kernel": "k_stream<ATOMIC_LOCUS> (derive + classify + per-locus count)", "avg_launch_ms": round(fms, 4), "launches": int(sf["submits"]),
                                 "records_per_launch": n_records, "algorithmic_bytes_per_launch": int(survey_bytes),
                                 "achieved": round(survey_bytes / (fms * 1e-3) / 1e9, 2) if fms > 0 else 0.0, "unit": "GB/s",

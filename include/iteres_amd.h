@@ -243,7 +243,8 @@ int itx_engine_get_stats(itx_engine *e, itx_stats *out);
  * i inflated to exactly usize bytes, else a small positive code (the data is damaged or the decoder declined it —
  * the caller's zlib has the last word, as in the reference). Synchronous; one calling thread per inflater. */
 typedef struct itx_inflater itx_inflater;
-#define ITX_BAMWIN_LANES 4        /* pushes that may be in flight at once (push_begin's s) */
+#define ITX_BAMWIN_LANES 8        /* pushes that may be in flight at once (push_begin's s); ITX_PUSHES (environment) says how many an inflater sets up */
+#define ITX_BAMWIN_LANES_DEFAULT 4
 #define ITX_BAMWIN_WINDOWS 48     /* windows of inflated bytes (w): the decode may run this far ahead of the consumer (a window's
                                    * buffer is allocated when it is first pushed into: 288 GB of HBM is room for a long lead) */
 typedef struct itx_bgzf_block {
@@ -329,6 +330,31 @@ int itx_xaveto_set_tidmap(itx_xaveto *x, const int32_t *tid2chrom, int n_tid);
 int32_t *itx_xaveto_hits(itx_xaveto *x);
 void *itx_xaveto_stream(itx_xaveto *x);
 int itx_bamwin_xa_veto(itx_inflater *h, itx_xaveto *x, size_t first, size_t n, uint64_t *n_vetoed, uint64_t *n_hard);
+
+/* ---- -R (remove redundant reads) on the device --------------------------------------------------------------------
+ * Replaces generic.c:907-919 (filter copy 544-556): the `dup` hash of "chr:start:end:strand" keys and the `continue` behind
+ * it. As a rule per record, records numbered in file order: one with MAPQ >= -Q is dropped iff an earlier one with MAPQ >= -Q
+ * has the same (chromosome name, start, end, strand); one with MAPQ < -Q looks up the key of the last MAPQ >= -Q record before
+ * it and is always dropped — except the very first record to reach that point of the loop when it comes before any MAPQ >= -Q
+ * record (the reference's key buffer then holds no record's key: modelled as a key no record has). Dropped records get
+ * ITX_F5_NOLOOKUP in their flag5 (the engine counts them up to reads_mapped(_unique) and does not look them up); the caller
+ * corrects cnt[11] by *dup_unique. csrc/itx_dedup.hip: a hash table in HBM that only ever compares FULL keys (hashes pick
+ * cells), grown by rehashing; at most 2^32 - 1 records per run.
+ *   create     chrom_size[n_chrom] as for itx_table_create; p: mapq_min, extension, isize_max, treat_pe_as_se,
+ *              discard_half_mapped; first_cells: a first size for the table (it grows)
+ *   set_tidmap the BAM header in use: tid2chrom as for itx_engine_set_tidmap, tid2name[t] an id of the (renamed) reference
+ *              name that is equal for equal strings over all files of the run (< 2^31)
+ *   run        the next n records of the stream as DEVICE arrays (mpos / isize NULL: no record is paired), in file order,
+ *              window after window; synchronous
+ *   itx_bamwin_dedup   run over all records of the inflater's last parsed window */
+typedef struct itx_dedup itx_dedup;
+int itx_dedup_create(int device, const int64_t *chrom_size, int n_chrom, const itx_params *p, size_t first_cells, itx_dedup **out);
+void itx_dedup_destroy(itx_dedup *d);
+int itx_dedup_set_tidmap(itx_dedup *d, const int32_t *tid2chrom, const uint32_t *tid2name, int n_tid);
+int itx_dedup_run(itx_dedup *d, const int32_t *tid, const int32_t *pos, const int32_t *tmpend, const uint8_t *mapq, uint8_t *flag5, const int32_t *mpos,
+                  const int32_t *isize, size_t n);
+int itx_dedup_counts(itx_dedup *d, uint64_t *dup_unique, uint64_t *dropped, uint64_t *keys);
+int itx_bamwin_dedup(itx_inflater *h, itx_dedup *d);
 
 /* ITX_TIMING: what the device decoder measured about itself (pushes, mean duration of the two passes, device allocations),
  * one line on stderr; also printed when the process exits normally. */

@@ -323,6 +323,18 @@ __global__ void k_warm(uint32_t *p)
 
 static void report_at_exit();
 
+// lanes an inflater sets up (streams, events, reserved scratch): ITX_PUSHES, 1 .. ITX_BAMWIN_LANES
+static int lanes_in_use()
+{
+    static int v;
+    if (!v) {
+        const char *e = getenv("ITX_PUSHES");
+        const int x = e ? atoi(e) : 0;
+        v = x >= 1 && x <= ITX_BAMWIN_LANES ? x : ITX_BAMWIN_LANES_DEFAULT;
+    }
+    return v;
+}
+
 struct itx_inflater {
     int device;
     hipStream_t st[2];
@@ -399,7 +411,7 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     SETUP_TICK("first two streams");
     for (int k = 0; k < 4; k++) INF_HIP(hipEventCreate(&h->ev[k]));
     for (int k = 0; k < 2; k++) INF_HIP(hipEventCreate(&h->ev_res_end[k]));
-    for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
+    for (int k = 0; k < lanes_in_use(); k++) {
         INF_HIP(hipStreamCreateWithFlags(&h->lane[k].st, hipStreamNonBlocking));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].copied, hipEventDisableTiming));
         for (int q = 0; q < 3; q++) INF_HIP(hipEventCreate(&h->lane[k].ev[q]));
@@ -635,7 +647,7 @@ static int check_blocks(const itx_bgzf_block *blk, size_t n_blk, size_t comp_len
 }
 
 #define BAD_W(w) ((w) < 0 || (w) >= ITX_BAMWIN_WINDOWS)
-#define BAD_S(s) ((s) < 0 || (s) >= ITX_BAMWIN_LANES)
+#define BAD_S(s) ((s) < 0 || (s) >= lanes_in_use())
 
 /* push, first half: everything is enqueued on lane s's stream and the call returns; the caller's buffers are in use until
  * itx_bamwin_push_copied (comp) / this call's return (blk) */
@@ -742,7 +754,8 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
     if (!h || !n_windows || max_blocks == 0 || max_blocks > 0x7fffffffu || max_bytes + WIN_HEAD > 0xfffffff0u) return ITX_E_ARG;
     if (h->arena) return ITX_E_STATE;
     INF_HIP(hipSetDevice(h->device));
-    for (int k = 0; k < ITX_BAMWIN_LANES; k++)
+    const int n_lanes = lanes_in_use();
+    for (int k = 0; k < n_lanes; k++)
         if (h->lane[k].busy || h->lane[k].d_comp) return ITX_E_STATE;
     size_t free_b = 0, total_b = 0;
     INF_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -759,7 +772,7 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
     const size_t sz_comp = al(comp_bytes + 64), sz_status = al(max_blocks), sz_blk = al(max_blocks * sizeof(itx_bgzf_block)), sz_lit = al(max_blocks * (size_t)SCR_STRIDE),
                  sz_meta = al(3 * max_blocks * 4);
     const size_t lane_bytes = sz_comp + sz_status + sz_blk + sz_lit + sz_meta;
-    const size_t total = lane_bytes * ITX_BAMWIN_LANES + per * n;
+    const size_t total = lane_bytes * (size_t)n_lanes + per * n;
     uint8_t *base = nullptr;
     const double t0 = wall_now();
     hipError_t he = hipMalloc((void **)&base, total);
@@ -772,7 +785,7 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
     h->arena = base;
     h->n_reserved_win = (int)n;
     uint8_t *p = base;
-    for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
+    for (int k = 0; k < n_lanes; k++) {
         auto &Ln = h->lane[k];
         Ln.d_comp = p; p += sz_comp; Ln.comp_cap = comp_bytes + 64;
         Ln.d_status = p; p += sz_status; Ln.status_cap = max_blocks;
@@ -1053,6 +1066,13 @@ extern "C" int itx_bamwin_xa_veto(itx_inflater *h, itx_xaveto *x, size_t first, 
     const int w = h->parsed_w;
     return itx_xaveto_run(x, h->win[w].buf, h->d_recoff + first, h->d_xa + first, h->d_tid + first, h->d_pos + first, h->d_end + first, h->d_f5 + first,
                           h->d_mpos + first, h->d_isize + first, n, n_vetoed, n_hard);
+}
+
+/* -R over all records of the last parsed window (csrc/itx_dedup.hip): the dropped ones get ITX_F5_NOLOOKUP where the window's flags lie */
+extern "C" int itx_bamwin_dedup(itx_inflater *h, itx_dedup *d)
+{
+    if (!h || !d) return ITX_E_ARG;
+    return itx_dedup_run(d, h->d_tid, h->d_pos, h->d_end, h->d_mapq, h->d_f5, h->d_mpos, h->d_isize, h->n_rec);
 }
 
 extern "C" int itx_bamwin_device_batch(itx_inflater *h, size_t first, int with_mates, itx_batch *out)

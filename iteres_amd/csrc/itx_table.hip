@@ -25,7 +25,7 @@
 #include <atomic>
 #include <numeric>
 #include <thread>
-#include <unordered_map>
+#include <set>
 #include <vector>
 
 static thread_local char g_err[512];
@@ -84,6 +84,21 @@ static void for_each_chrom(int n_chrom, F fn)
     for (auto &t : th) t.join();
 }
 
+// Runs fn(t, lo, hi) over n items cut into contiguous slices, one per host thread (at most 16, at least `grain` items each).
+template <class F>
+static size_t for_slices(size_t n, size_t grain, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? hw : 1;
+    if (nt > 16) nt = 16;
+    if (nt > n / grain + 1) nt = n / grain + 1;
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; t++) th.emplace_back([&, t]() { fn(t, n * t / nt, n * (t + 1) / nt); });
+    fn((size_t)0, (size_t)0, n / nt);
+    for (auto &x : th) x.join();
+    return nt;
+}
+
 struct Carver {
     size_t off = 0;
     size_t take(size_t bytes)
@@ -125,96 +140,84 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
         }
     double tb0 = 0;
     tb_tick("start", &tb0);
-    // validate rows as binKeeperAdd would, bucket by chromosome
+    // validate rows as binKeeperAdd would, bucket by chromosome (slices of the rows in parallel; the FIRST bad row is reported)
     std::vector<uint32_t> chrom_cnt(n_chrom + 1, 0);
     std::vector<int> lvl(n_rows), bin(n_rows);
-    for (size_t i = 0; i < n_rows; i++) {
-        const itx_row &r = rows[i];
-        bool ok = r.chrom >= 0 && r.chrom < n_chrom && (int)chrom_size[r.chrom] != 0 && r.rep < n_rep && r.fam < n_fam &&
-                  r.cla < n_cla;
-        if (ok) {
-            int s = (int)r.start, e = (int)r.end, maxPos = (int)chrom_size[r.chrom];
-            ok = !(s < 0 || e > maxPos || s > e) && bin_of_range(s, e, &lvl[i], &bin[i]);
-        }
-        if (!ok) {
-            if (bad_row) *bad_row = i;
-            itx_set_error("itx_table_create: row %zu (chrom %d, %u-%u) is outside its chromosome or has bad ids", i,
-                          r.chrom, r.start, r.end);
+    {
+        std::vector<std::vector<uint32_t>> cnt_t(16, std::vector<uint32_t>((size_t)n_chrom + 1, 0));
+        std::vector<size_t> bad_t(16, SIZE_MAX);
+        for_slices(n_rows, 65536, [&](size_t t, size_t lo, size_t hi) {
+            std::vector<uint32_t> &cc = cnt_t[t];
+            for (size_t i = lo; i < hi; i++) {
+                const itx_row &r = rows[i];
+                bool ok = r.chrom >= 0 && r.chrom < n_chrom && (int)chrom_size[r.chrom] != 0 && r.rep < n_rep && r.fam < n_fam && r.cla < n_cla;
+                if (ok) {
+                    int s = (int)r.start, e = (int)r.end, maxPos = (int)chrom_size[r.chrom];
+                    ok = !(s < 0 || e > maxPos || s > e) && bin_of_range(s, e, &lvl[i], &bin[i]);
+                }
+                if (!ok) {
+                    bad_t[t] = i;
+                    return;
+                }
+                cc[(size_t)r.chrom + 1]++;
+            }
+        });
+        size_t bad = SIZE_MAX;
+        for (size_t t = 0; t < 16; t++) bad = std::min(bad, bad_t[t]);
+        if (bad != SIZE_MAX) {
+            const itx_row &r = rows[bad];
+            if (bad_row) *bad_row = bad;
+            itx_set_error("itx_table_create: row %zu (chrom %d, %u-%u) is outside its chromosome or has bad ids", bad, r.chrom, r.start, r.end);
             return ITX_E_RANGE;
         }
-        chrom_cnt[r.chrom + 1]++;
+        for (size_t t = 0; t < 16; t++)
+            for (int c = 0; c <= n_chrom; c++) chrom_cnt[(size_t)c] += cnt_t[t][(size_t)c];
     }
     tb_tick("validate + bucket", &tb0);
-    // units: distinct (rep, fam, cla) triples, ordered by (rep, fam, cla). There are few of them (tens of thousands for
-    // rmsk): collect the distinct triples through a hash, sort those, then one lookup per row.
+    // units: distinct (rep, fam, cla) triples, ordered by (rep, fam, cla). Nearly every repName has ONE family and class: a
+    // slice of the rows remembers the first (fam, cla) it meets per name in a plain array, and only a row whose name has
+    // been seen with another pair goes through a (small) set — no hashing per row (the per-row hash lookups of the first
+    // version were 0.17 s of a 0.45 s build). The units of a name are neighbours in sorted order, so a row's unit is its
+    // name's first unit plus a scan over that name's handful of units.
     std::vector<uint32_t> unit_of_row(n_rows);
     std::vector<uint4> unit_ids;
     {
-        struct TripleHash {
-            size_t operator()(const std::array<uint32_t, 3> &k) const
-            {
-                uint64_t h = ((uint64_t)k[0] * 0x9e3779b97f4a7c15ull) ^ ((uint64_t)k[1] << 32 | k[2]) * 0xc2b2ae3d27d4eb4full;
-                return (size_t)(h ^ (h >> 29));
+        typedef std::array<uint32_t, 3> Triple;
+        std::vector<std::vector<Triple>> found(16);
+        for_slices(n_rows, 65536, [&](size_t t, size_t lo, size_t hi) {
+            std::vector<uint64_t> first_fc((size_t)n_rep, 0);                 // (fam << 32 | cla) + 1 of the name's first row in this slice
+            std::set<Triple> extra;                                            // triples beyond a name's first pair (few)
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t fc = ((uint64_t)rows[i].fam << 32 | rows[i].cla) + 1;
+                uint64_t &f = first_fc[rows[i].rep];
+                if (f == fc) continue;
+                const Triple k = {rows[i].rep, rows[i].fam, rows[i].cla};
+                if (f == 0) {
+                    f = fc;
+                    found[t].push_back(k);
+                } else {
+                    extra.insert(k);
+                }
             }
-        };
-        // the distinct triples, found by slices of the rows in parallel and united; their ids are their ranks in sorted
-        // order, so who finds what first does not matter
-        typedef std::unordered_map<std::array<uint32_t, 3>, uint32_t, TripleHash> TripleMap;
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, n_rows / 65536 + 1}));
-        std::vector<std::vector<std::array<uint32_t, 3>>> found(n_thr);
-        auto slice = [&](size_t t, size_t &lo, size_t &hi) {
-            lo = n_rows * t / n_thr;
-            hi = n_rows * (t + 1) / n_thr;
-        };
-        {
-            std::vector<std::thread> th;
-            for (size_t t = 0; t < n_thr; t++)
-                th.emplace_back([&, t]() {
-                    size_t lo, hi;
-                    slice(t, lo, hi);
-                    TripleMap seen;
-                    seen.reserve(1 << 14);
-                    std::array<uint32_t, 3> last = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-                    for (size_t i = lo; i < hi; i++) {
-                        const std::array<uint32_t, 3> k = {rows[i].rep, rows[i].fam, rows[i].cla};
-                        if (k == last) continue;
-                        last = k;
-                        if (seen.emplace(k, 0u).second) found[t].push_back(k);
-                    }
-                });
-            for (auto &x : th) x.join();
-        }
-        std::vector<std::array<uint32_t, 3>> triples;
+            found[t].insert(found[t].end(), extra.begin(), extra.end());
+        });
+        std::vector<Triple> triples;
         for (auto &f : found) triples.insert(triples.end(), f.begin(), f.end());
         std::sort(triples.begin(), triples.end());
         triples.erase(std::unique(triples.begin(), triples.end()), triples.end());
-        TripleMap id_of;
-        id_of.reserve(triples.size() * 2 + 16);
         unit_ids.resize(triples.size());
-        for (size_t k = 0; k < triples.size(); k++) {
-            id_of.emplace(triples[k], (uint32_t)k);
+        std::vector<uint32_t> first_unit((size_t)n_rep + 1, 0);               // the first unit of every name (names without rows: unused)
+        for (size_t k = triples.size(); k-- > 0;) {
             unit_ids[k] = make_uint4(triples[k][0], triples[k][1], triples[k][2], 0);
+            first_unit[triples[k][0]] = (uint32_t)k;
         }
-        {
-            std::vector<std::thread> th;
-            for (size_t t = 0; t < n_thr; t++)
-                th.emplace_back([&, t]() {
-                    size_t lo, hi;
-                    slice(t, lo, hi);
-                    std::array<uint32_t, 3> last = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-                    uint32_t last_id = 0;
-                    for (size_t i = lo; i < hi; i++) {
-                        const std::array<uint32_t, 3> k = {rows[i].rep, rows[i].fam, rows[i].cla};
-                        if (k != last) {
-                            last = k;
-                            last_id = id_of.find(k)->second;
-                        }
-                        unit_of_row[i] = last_id;
-                    }
-                });
-            for (auto &x : th) x.join();
-        }
+        for_slices(n_rows, 65536, [&](size_t, size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) {
+                uint32_t u = first_unit[rows[i].rep];
+                while (unit_ids[u].y != rows[i].fam || unit_ids[u].z != rows[i].cla) u++;      // (the triple is there: it was collected above)
+                unit_of_row[i] = u;
+            }
+        });
     }
     const uint32_t n_units = (uint32_t)unit_ids.size();
     std::vector<uint64_t> covoff(n_rep + 1);
@@ -284,37 +287,109 @@ extern "C" int itx_table_create(const itx_row *rows, size_t n_rows, const int64_
     std::vector<int32_t> orig(n_rows);
     std::vector<uint32_t> row_unit(n_rows);
     std::vector<int32_t> csize(n_chrom);
-    for_each_chrom(n_chrom, [&](int c) {
-        csize[c] = (int32_t)chrom_size[c];
-        uint32_t lo = chrom_off[c], hi = chrom_off[c + 1];
-        int32_t pm = INT32_MIN;
-        for (uint32_t k = lo; k < hi; k++) {
-            const itx_row &r = rows[order[k]];
-            ItxIv &d = iv[k];
-            d.s = (int32_t)r.start;
-            d.e = (int32_t)r.end;
-            d.pbelow = pm;
-            pm = std::max(pm, d.e);
-            d.cs = r.cons_start;
-            const uint32_t len = rep_len[r.rep];
-            const uint32_t u = unit_of_row[order[k]];
-            d.jcap = std::min(r.cons_end, len);
-            d.covslot = unit_slot[u];
-            d.zslot = unit_slot[u] + len;
-            d.rank = rank_of_row[order[k]];
-            orig[k] = (int32_t)order[k];
-            row_unit[k] = u;
+    for (int c = 0; c < n_chrom; c++) csize[c] = (int32_t)chrom_size[c];
+    // rows: slices of the sorted order in parallel. pbelow (the running maximum of the ends of a chromosome's rows below) crosses
+    // slice boundaries: a first pass takes every slice's maximum over the rows of its LAST chromosome, a short serial pass turns
+    // those into what each slice starts with, the second pass fills the rows. (One thread per chromosome left chr1's 8 % of the
+    // rows to one thread: 0.09 s.)
+    {
+        struct SliceSum {
+            int32_t last_chrom, last_max;      // the slice's last chromosome and the maximum end over its rows of it
+            bool one_chrom;                    // the whole slice lies in that chromosome
+        };
+        std::vector<SliceSum> ss(16, SliceSum{-1, INT32_MIN, false});
+        const size_t nt = for_slices(n_rows, 32768, [&](size_t t, size_t lo, size_t hi) {
+            if (lo >= hi) return;
+            const int32_t lc = rows[order[hi - 1]].chrom;
+            int32_t mx = INT32_MIN;
+            size_t k = hi;
+            while (k > lo && rows[order[k - 1]].chrom == lc) {
+                mx = std::max(mx, (int32_t)rows[order[k - 1]].end);
+                k--;
+            }
+            ss[t] = SliceSum{lc, mx, k == lo};
+        });
+        std::vector<int32_t> carry_in(16, INT32_MIN);      // maximum end over the rows of the slice's FIRST chromosome that lie before the slice
+        {
+            int32_t cur_chrom = -1, cur_max = INT32_MIN;
+            for (size_t t = 0; t < nt; t++) {
+                const size_t lo = n_rows * t / nt, hi = n_rows * (t + 1) / nt;
+                if (lo >= hi) continue;
+                const int32_t fc = rows[order[lo]].chrom;
+                carry_in[t] = fc == cur_chrom ? cur_max : INT32_MIN;
+                if (ss[t].one_chrom && ss[t].last_chrom == cur_chrom) cur_max = std::max(cur_max, ss[t].last_max);
+                else {
+                    cur_chrom = ss[t].last_chrom;
+                    cur_max = ss[t].last_max;
+                }
+            }
         }
-        uint32_t nb = bin_off[c + 1] - bin_off[c];
-        uint32_t k = lo, m = lo;
+        for_slices(n_rows, 32768, [&](size_t t, size_t lo, size_t hi) {
+            int32_t pm = carry_in[t], cur = lo < hi ? rows[order[lo]].chrom : -1;
+            for (size_t k = lo; k < hi; k++) {
+                const itx_row &r = rows[order[k]];
+                if (r.chrom != cur) {
+                    cur = r.chrom;
+                    pm = INT32_MIN;
+                }
+                ItxIv &d = iv[k];
+                d.s = (int32_t)r.start;
+                d.e = (int32_t)r.end;
+                d.pbelow = pm;
+                pm = std::max(pm, d.e);
+                d.cs = r.cons_start;
+                const uint32_t len = rep_len[r.rep];
+                const uint32_t u = unit_of_row[order[k]];
+                d.jcap = std::min(r.cons_end, len);
+                d.covslot = unit_slot[u];
+                d.zslot = unit_slot[u] + len;
+                d.rank = rank_of_row[order[k]];
+                orig[k] = (int32_t)order[k];
+                row_unit[k] = u;
+            }
+        });
+    }
+    // the binned index: slices of ALL bins in parallel; a slice finds its place in the rows by bisection (starts and prefix-max
+    // ends both rise along a chromosome) and sweeps on from there
+    {
+        const size_t n_bins = bin_off[n_chrom];
         auto pmax = [&](uint32_t r) { return std::max(iv[r].pbelow, iv[r].e); };
-        for (uint32_t b = 0; b < nb; b++) {
-            int64_t bound = (int64_t)b << shift;
-            while (k < hi && (int64_t)iv[k].s < bound) k++;          // first row starting at or after the bin
-            while (m < hi && (int64_t)pmax(m) <= bound) m++;         // first row whose prefix-max end passes the bin start
-            bl[bin_off[c] + b] = make_uint2(k, m);
-        }
-    });
+        for_slices(n_bins, 65536, [&](size_t, size_t g0, size_t g1) {
+            int c = (int)(std::upper_bound(bin_off.begin(), bin_off.end(), (uint32_t)g0) - bin_off.begin()) - 1;
+            uint32_t k = 0, m = 0;
+            bool fresh = true;
+            for (size_t g = g0; g < g1; g++) {
+                while (g >= bin_off[c + 1]) {
+                    c++;
+                    fresh = true;
+                }
+                const uint32_t lo = chrom_off[c], hi = chrom_off[c + 1];
+                const int64_t bound = (int64_t)(g - bin_off[c]) << shift;
+                if (fresh) {
+                    // first row starting at or after the bin; first row whose prefix-max end passes the bin start
+                    uint32_t a = lo, b = hi;
+                    while (a < b) {
+                        const uint32_t mid = a + (b - a) / 2;
+                        if ((int64_t)iv[mid].s < bound) a = mid + 1;
+                        else b = mid;
+                    }
+                    k = a;
+                    a = lo, b = hi;
+                    while (a < b) {
+                        const uint32_t mid = a + (b - a) / 2;
+                        if ((int64_t)pmax(mid) <= bound) a = mid + 1;
+                        else b = mid;
+                    }
+                    m = a;
+                    fresh = false;
+                } else {
+                    while (k < hi && (int64_t)iv[k].s < bound) k++;
+                    while (m < hi && (int64_t)pmax(m) <= bound) m++;
+                }
+                bl[g] = make_uint2(k, m);
+            }
+        });
+    }
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {

@@ -28,6 +28,7 @@ EXPORTS = [
     "itx_bamwin_parse", "itx_bamwin_fetch", "itx_bamwin_bytes", "itx_bamwin_tids", "itx_bamwin_device_batch",
     "itx_engine_submit_device_own", "itx_engine_wait_own",
     "itx_engine_partial_buffers", "itx_inflater_reserve", "itx_inflater_last_resolve_all_ms", "itx_timing_report", "itx_xaveto_create", "itx_xaveto_destroy", "itx_xaveto_set_tidmap", "itx_xaveto_hits", "itx_xaveto_stream", "itx_bamwin_xa_veto", "itx_comm_create", "itx_comm_destroy", "itx_comm_reduce_sum",
+    "itx_dedup_create", "itx_dedup_destroy", "itx_dedup_set_tidmap", "itx_dedup_run", "itx_dedup_counts", "itx_bamwin_dedup",
 ]
 
 
@@ -130,6 +131,12 @@ def load():
     L.itx_bamwin_parse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.itx_bamwin_fetch.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(Staging), C.c_size_t, C.c_void_p, C.c_void_p]
     L.itx_bamwin_bytes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.itx_dedup_create.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(Params), C.c_size_t, C.POINTER(C.c_void_p)]
+    L.itx_dedup_destroy.argtypes = [C.c_void_p]
+    L.itx_dedup_destroy.restype = None
+    L.itx_dedup_set_tidmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.itx_dedup_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.itx_dedup_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.itx_pinned_alloc.argtypes = [C.c_size_t]
     L.itx_pinned_alloc.restype = C.c_void_p
     L.itx_pinned_free.argtypes = [C.c_void_p]
@@ -383,6 +390,48 @@ class Inflater:
         if self._h:
             load().itx_inflater_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Dedup:
+    """-R on the device (include/iteres_amd.h itx_dedup_*, replacing generic.c:907-919): `run` takes the next records of the
+    stream as torch DEVICE tensors (int32 tid / pos / tmpend, uint8 mapq / flag5, optional int32 mpos / isize) and ORs
+    ITX_F5_NOLOOKUP into flag5 for the records the reference would `continue` over."""
+
+    def __init__(self, chrom_size, params: dict | None = None, first_cells: int = 1 << 16, device: int = 0):
+        L = load()
+        q = dict(mapq_min=10, min_cov=1e-4, extension=150, isize_max=500, treat_pe_as_se=False, discard_half_mapped=False)
+        q.update(params or {})
+        p = Params(int(q["mapq_min"]), float(q["min_cov"]), int(q["extension"]), int(q["isize_max"]), int(bool(q["treat_pe_as_se"])),
+                   int(bool(q["discard_half_mapped"])), MODE_STAT, ACCUM_DEFAULT)
+        cs = np.ascontiguousarray(chrom_size, np.int64)
+        self._h = C.c_void_p()
+        _chk(L.itx_dedup_create(device, _p(cs), len(cs), C.byref(p), first_cells, C.byref(self._h)), "itx_dedup_create")
+
+    def set_tidmap(self, tid2chrom, tid2name):
+        a = np.ascontiguousarray(tid2chrom, np.int32)
+        b = np.ascontiguousarray(tid2name, np.uint32)
+        _chk(load().itx_dedup_set_tidmap(self._h, _p(a), _p(b), len(a)), "itx_dedup_set_tidmap")
+
+    def run(self, tid, pos, tmpend, mapq, flag5, mpos=None, isize=None):
+        n = int(tid.numel())
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _chk(load().itx_dedup_run(self._h, ptr(tid), ptr(pos), ptr(tmpend), ptr(mapq), ptr(flag5), ptr(mpos), ptr(isize), n), "itx_dedup_run")
+
+    def counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _chk(load().itx_dedup_counts(self._h, C.byref(a), C.byref(b), C.byref(c)), "itx_dedup_counts")
+        return {"dup_unique": a.value, "dropped": b.value, "keys": c.value}
+
+    def close(self):
+        if self._h:
+            load().itx_dedup_destroy(self._h)
+            self._h = None
 
     def __del__(self):
         try:

@@ -47,17 +47,22 @@ struct aln_reader {
     size_t clen;              /* a window into one of the two raw buffers below                                 */
     /* raw read-ahead (raw_next): a reader thread freads the next compressed chunk while this one is being inflated */
 #define N_RAW_DEVICE (ITX_BAMWIN_LANES + 2)
-#define N_RAW_DEVICE_FILE 4
-    uint8_t *craw[N_RAW_DEVICE]; /* two for the host decoder. The device's, from a regular file: one being read, one being indexed, two whose
-                                  * pushes are copying (a buffer is free again once the pushes cut from it have COPIED their bytes: a block the
-                                  * device declines is read from the file once more); from a pipe: one per push in flight + 2, held until the push ends */
+#define N_RAW_DEVICE_FILE 5
+    uint8_t *craw[N_RAW_DEVICE]; /* two for the host decoder. The device's, from a regular file: one being indexed, one whose pushes are
+                                  * copying, the others read ahead (a buffer is free again once the pushes cut from it have COPIED their bytes: a
+                                  * block the device declines is read from the file once more); from a pipe: one per push in flight + 2, held
+                                  * until the push ends */
     uint32_t raw_lanes[N_RAW_DEVICE];   /* per buffer: the lanes whose pushes read their compressed bytes from it (bit s = lane s) */
     int n_raw, raw_cur;          /* raw_cur: the buffer cbuf points into */
-    size_t io_got;
+    size_t io_got[N_RAW_DEVICE];      /* bytes the reader put into each buffer */
+    long io_fill, io_take;       /* chunks read so far / taken by raw_next so far (chunk f lives in buffer f % n_raw) */
+    int io_eof_seen;             /* the reader has met a short read: it reads no further */
     int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
     size_t io_off, io_size;
     size_t raw_step;          /* bytes per read step (aln_raw_step) */
-    int io_on, io_state, io_stop, io_buf, io_done;   /* io_state: 0 idle, 1 requested, 2 ready; io_done: the file is read out */
+    void (*win_hook)(void *, size_t);   /* aln_set_window_hook */
+    void *win_hook_ctx;
+    int io_on, io_stop, io_done; /* io_done: the file is read out and its last chunk taken */
     /* a share of the file (aln_open_range; one rank of a multi-GPU job): the stream starts at the BGZF block at byte
      * rg_lo_block of the file, rg_skip inflated bytes into it, and ends where the next share starts: rg_end_off bytes into
      * the block at rg_end_block (SIZE_MAX: at the end of the file) */
@@ -438,15 +443,29 @@ size_t aln_raw_step(size_t left)
     const size_t full = RAW_STEP, need = ((left + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1)) + ((size_t)1 << 20);
     return need < full ? need : full;
 }
+/* how many chunks the reader may be ahead of the one raw_next hands out next: from a regular file as many as there are
+ * buffers beyond the one being indexed and the one whose pushes may still be copying (the reader used to wait for raw_next
+ * after every chunk: while the producer sat in a push the file was not read, and then the producer waited for the file —
+ * a quarter of the record loop of a BAM the device takes at the rate the page cache delivers it); else one */
+static long io_ahead(const aln_reader *r) { return r->n_raw == N_RAW_DEVICE_FILE ? r->n_raw - 3 : 0; }
+
 static void *io_main(void *arg)
 {
     aln_reader *r = arg;
     pthread_mutex_lock(&r->io_mu);
     for (;;) {
-        while (r->io_state != 1 && !r->io_stop) pthread_cond_wait(&r->io_cv, &r->io_mu);
+        /* chunk io_fill goes into buffer io_fill % n_raw, last used by chunk io_fill - n_raw: raw_next has long moved on from it */
+        while (!r->io_stop && (r->io_eof_seen || r->io_fill - r->io_take > io_ahead(r))) pthread_cond_wait(&r->io_cv, &r->io_mu);
         if (r->io_stop) break;
-        uint8_t *dst = r->craw[r->io_buf] + RAW_HEAD;
+        const int b = (int)(r->io_fill % r->n_raw);
+        const uint32_t lanes = r->raw_lanes[b];
+        r->raw_lanes[b] = 0;
         pthread_mutex_unlock(&r->io_mu);
+        /* ... and the pushes cut from it have copied their bytes (all of them were begun before the chunk after it was taken) */
+        for (int sl = 0; sl < ITX_BAMWIN_LANES; sl++)
+            if (lanes >> sl & 1u) DEV_CHK(dev.push_copied(dev.ctx, sl), "push_copied");
+        if (!r->craw[b]) r->craw[b] = buf_alloc(RAW_HEAD + r->raw_step + 64);       /* page-locking a buffer takes a while: not under the lock */
+        uint8_t *dst = r->craw[b] + RAW_HEAD;
         size_t got;
         if (r->io_fd >= 0) {
             /* a regular file: the step is read as eight slices at once (one thread copying out of the page cache delivers
@@ -484,8 +503,9 @@ static void *io_main(void *arg)
             got = fread(dst, 1, r->raw_step, r->f);
         }
         pthread_mutex_lock(&r->io_mu);
-        r->io_got = got;
-        r->io_state = 2;
+        r->io_got[b] = got;
+        if (got < r->raw_step) r->io_eof_seen = 1;                 /* a short read: end of file (or an error, same thing here) */
+        r->io_fill++;
         pthread_cond_broadcast(&r->io_cv);
     }
     pthread_mutex_unlock(&r->io_mu);
@@ -518,47 +538,28 @@ static size_t raw_next(aln_reader *r)
             if (r->dev && r->io_fd >= 0 && dev.push_copied) r->n_raw = N_RAW_DEVICE_FILE;
         }
         r->raw_step = r->io_fd >= 0 ? aln_raw_step(r->io_size > r->io_off ? r->io_size - r->io_off : 0) : RAW_STEP;
-        r->craw[0] = buf_alloc(RAW_HEAD + r->raw_step + 64);       /* the others when the rotation first reaches them */
         pthread_mutex_init(&r->io_mu, NULL);
         pthread_cond_init(&r->io_cv, NULL);
-        r->io_buf = 0;
-        r->io_state = 1;
+        r->io_fill = r->io_take = 0;
+        r->io_eof_seen = 0;
         r->io_stop = 0;
         if (pthread_create(&r->io_thread, NULL, io_main, r) != 0) die("cannot start the file read-ahead thread");
         r->io_on = 1;
     }
     pthread_mutex_lock(&r->io_mu);
-    while (r->io_state != 2) pthread_cond_wait(&r->io_cv, &r->io_mu);
-    const size_t got = r->io_got;
-    uint8_t *nb = r->craw[r->io_buf];
+    while (r->io_fill <= r->io_take) pthread_cond_wait(&r->io_cv, &r->io_mu);
+    const int b = (int)(r->io_take % r->n_raw);
+    const size_t got = r->io_got[b];
+    uint8_t *nb = r->craw[b];
     if (r->clen > RAW_HEAD) die("BGZF: %zu bytes left over by the block indexer", r->clen);    /* cannot happen: < one block */
     if (r->clen) memcpy(nb + RAW_HEAD - r->clen, r->cbuf, r->clen);
     r->cbuf = nb + RAW_HEAD - r->clen;
     r->clen += got;
     r->io_abs_end += got;
-    r->raw_cur = r->io_buf;
-    r->io_buf = (r->io_buf + 1) % r->n_raw;
-    if (r->raw_lanes[r->io_buf]) {
-        /* the buffer the reader fills next: the pushes cut from it, n_raw - 1 chunks ago, have long copied their bytes */
-        pthread_mutex_unlock(&r->io_mu);
-        for (int sl = 0; sl < ITX_BAMWIN_LANES; sl++)
-            if (r->raw_lanes[r->io_buf] >> sl & 1u) DEV_CHK(dev.push_copied(dev.ctx, sl), "push_copied");
-        r->raw_lanes[r->io_buf] = 0;
-        pthread_mutex_lock(&r->io_mu);
-    }
-    if (got == r->raw_step) {
-        if (!r->craw[r->io_buf]) {
-            pthread_mutex_unlock(&r->io_mu);                       /* page-locking a buffer takes a while: not under the lock */
-            uint8_t *fresh = buf_alloc(RAW_HEAD + r->raw_step + 64);
-            pthread_mutex_lock(&r->io_mu);
-            r->craw[r->io_buf] = fresh;
-        }
-        r->io_state = 1;                                          /* the other buffer is free: read on */
-        pthread_cond_broadcast(&r->io_cv);
-    } else {
-        r->io_state = 0;
-        r->io_done = 1;                                           /* a short read: end of file (or an error, same thing here) */
-    }
+    r->raw_cur = b;
+    r->io_take++;
+    if (got < r->raw_step) r->io_done = 1;                         /* the reader has stopped behind this chunk */
+    pthread_cond_broadcast(&r->io_cv);                             /* a buffer further back has become the reader's */
     pthread_mutex_unlock(&r->io_mu);
     return got;
 }
@@ -658,9 +659,10 @@ static size_t bgzf_inflate_chunk(aln_reader *r, uint8_t **pbuf, size_t *pcap, si
 
 
 static void pf_request(aln_reader *r);
+static long pushes_in_flight(void);
 
 /* ---- the device decoder (aln_use_device): this side only moves compressed bytes in ------------------------------------
- * Chunk k of the file is pushed into window k % ITX_BAMWIN_WINDOWS of the device on lane k % ITX_BAMWIN_LANES (a lane = a
+ * Chunk k of the file is pushed into window k % ITX_BAMWIN_WINDOWS of the device on lane k % pushes_in_flight() (a lane = a
  * stream with its own scratch): that many pushes are kept in flight, so the Huffman pass of one chunk — a lane per block, latency-bound, most of the chip idle —
  * runs beside the token replay of the chunk before it. A block the device decoder flags is given to zlib here, whose verdict
  * is the reference's: inflated after all, its bytes are patched in; not inflatable, the stream ends in front of it
@@ -679,7 +681,7 @@ static void dev_begin(aln_reader *r)
     }
     const size_t max_bytes = dev.max_bytes ? dev.max_bytes : DEV_MAX_BYTES;
     const long k = r->dk_begin;
-    struct dev_job *j = &r->dj[k % ITX_BAMWIN_LANES];
+    struct dev_job *j = &r->dj[k % pushes_in_flight()];
     double tq = now_s();
     size_t got = 1;
     if (!r->dmore) got = raw_next(r);                              /* complete blocks of the last raw chunk are still waiting */
@@ -743,13 +745,17 @@ static void dev_begin(aln_reader *r)
     j->nb = nb_use;
     j->cbase = r->cbuf;
     j->cabs = r->io_fd >= 0 ? r->io_abs_end - r->clen : SIZE_MAX;
-    if (r->n_raw == N_RAW_DEVICE_FILE) r->raw_lanes[r->raw_cur] |= 1u << (k % ITX_BAMWIN_LANES);
+    if (r->n_raw == N_RAW_DEVICE_FILE && r->io_on) {
+        pthread_mutex_lock(&r->io_mu);
+        r->raw_lanes[r->raw_cur] |= 1u << (k % pushes_in_flight());
+        pthread_mutex_unlock(&r->io_mu);
+    }
     j->w = (int)(k % dev_nwin);
     j->last = damaged || share_done || (got == 0 && nb == 0);
     if (damaged && r->rg_on) r->rg_suspect = 1;
     static const uint8_t none[16];
     tq = now_s();
-    DEV_CHK(dev.push_begin(dev.ctx, j->w, (int)(k % ITX_BAMWIN_LANES), r->clen ? r->cbuf : none, off, r->dblk, nb_use), "push");
+    DEV_CHK(dev.push_begin(dev.ctx, j->w, (int)(k % pushes_in_flight()), r->clen ? r->cbuf : none, off, r->dblk, nb_use), "push");
     t_inflate += now_s() - tq;
     r->cbuf += off;
     r->clen -= off;
@@ -760,10 +766,10 @@ static void dev_begin(aln_reader *r)
 static void dev_end(aln_reader *r)
 {
     const long k = r->dk_ready;
-    struct dev_job *j = &r->dj[k % ITX_BAMWIN_LANES];
+    struct dev_job *j = &r->dj[k % pushes_in_flight()];
     size_t n_new = 0;
     const double tq = now_s();
-    DEV_CHK(dev.push_end(dev.ctx, (int)(k % ITX_BAMWIN_LANES), r->dstatus, &n_new), "push");
+    DEV_CHK(dev.push_end(dev.ctx, (int)(k % pushes_in_flight()), r->dstatus, &n_new), "push");
     int damaged = 0;
     for (size_t i = 0; i < j->nb; i++)
         if (r->dstatus[i]) {
@@ -805,7 +811,7 @@ static long pushes_in_flight(void)
     if (!v) {
         const char *e = getenv("ITX_PUSHES");
         const long x = e ? atol(e) : 0;
-        v = x >= 1 && x <= ITX_BAMWIN_LANES ? x : ITX_BAMWIN_LANES;
+        v = x >= 1 && x <= ITX_BAMWIN_LANES ? x : ITX_BAMWIN_LANES_DEFAULT;
     }
     return v;
 }
@@ -835,7 +841,7 @@ static void *dev_producer(void *arg)
         if (act == 1) {
             dev_begin(r);
             pthread_mutex_lock(&r->pf_mu);
-            if (r->dj[(r->dk_begin - 1) % ITX_BAMWIN_LANES].last) r->dinput_done = 1;
+            if (r->dj[(r->dk_begin - 1) % pushes_in_flight()].last) r->dinput_done = 1;
         } else {
             dev_end(r);
             pthread_mutex_lock(&r->pf_mu);
@@ -1311,8 +1317,7 @@ void aln_close(aln_reader *r)
         }
     if (r->io_on) {
         pthread_mutex_lock(&r->io_mu);
-        while (r->io_state == 1) pthread_cond_wait(&r->io_cv, &r->io_mu);      /* let a read in flight land */
-        r->io_stop = 1;
+        r->io_stop = 1;                                                        /* (a read in flight lands first: the thread looks when it is back) */
         pthread_cond_broadcast(&r->io_cv);
         pthread_mutex_unlock(&r->io_mu);
         pthread_join(r->io_thread, NULL);
@@ -1623,6 +1628,7 @@ static int dev_ensure_records(aln_reader *r)
                 r->dlast = 1;                                  /* bam.c:186-190: nothing after this window counts */
                 if (r->rg_on) r->rg_suspect = 1;               /* ... of the whole file: the other shares must not count either */
             }
+            if (r->win_hook && r->dn_rec) r->win_hook(r->win_hook_ctx, r->dn_rec);
             continue;
         }
         if (r->dlast || r->eof) {                              /* end of input (a truncated tail record is dropped) */
@@ -1652,6 +1658,12 @@ int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen)
     return 1;
 }
 
+void aln_set_window_hook(aln_reader *r, void (*fn)(void *ctx, size_t n_rec), void *ctx)
+{
+    r->win_hook = fn;
+    r->win_hook_ctx = ctx;
+}
+
 void aln_readahead(aln_reader *r)
 {
     if (!r->is_sam && !r->pf_on && !r->eof) pf_start(r);
@@ -1666,9 +1678,9 @@ int aln_device_xa_veto(aln_reader *r, itx_xaveto *x, size_t n, uint64_t *n_vetoe
     return 0;
 }
 
-void aln_device_rewind(aln_reader *r)
+void aln_device_rewind(aln_reader *r, size_t n)
 {
-    if (r->dev && r->dparsed) r->drec_next = 0;
+    if (r->dev && r->dparsed) r->drec_next = n <= r->drec_next ? r->drec_next - n : 0;
 }
 
 int aln_device_exhausted(aln_reader *r) { return r->dev && !dev_ensure_records(r); }
@@ -1725,7 +1737,9 @@ static size_t dev_read_batch(aln_reader *r, itx_staging *st, size_t cap, aln_sid
                 for (long i = (long)i0; i < (long)i1; i++)
                     if (want_q || xa[i]) {
                         int a1 = 0, x1 = 0;
+                        const uint8_t marked = st->flag5[n + (size_t)i] & ITX_F5_NOLOOKUP;       /* set on the device (-R): the record's bytes do not hold it */
                         bam_parse_one(raw + (ro[i] - lo), n + (size_t)i, st, side, &a1, &x1);   /* the same field values again, plus the strings */
+                        st->flag5[n + (size_t)i] |= marked;
                     }
             }
             side->has_strings = 1;                 /* entries outside [i0, i1) were never written: still NULL */

@@ -114,11 +114,14 @@ size_t aln_raw_step(size_t left);           /* bytes per read step of a regular 
  * decoder, end of input, or in the middle of a window: use aln_read_batch (which then stops at the window's end).
  * aln_read_batch_device: the next <= cap records of that window as device arrays, valid until the next reader call. */
 int aln_device_window(aln_reader *r, int *flags, const uint8_t **tid_seen);
+/* Device decoder only: fn(ctx, n_rec) is called once for every window right after its records have been located and parsed, in
+ * file order, before any of them is handed out (-R on the device marks its duplicates there: stream.c) */
+void aln_set_window_hook(aln_reader *r, void (*fn)(void *ctx, size_t n_rec), void *ctx);
 size_t aln_read_batch_device(aln_reader *r, size_t cap, itx_batch *b);
 /* the XA veto over the batch aln_read_batch_device has just handed out (its chosen rows are in the veto object's buffer);
  * aln_device_rewind: hand the current window's records out again from its first one (the host route after all) */
 int aln_device_xa_veto(aln_reader *r, itx_xaveto *x, size_t n, uint64_t *n_vetoed, uint64_t *n_hard);
-void aln_device_rewind(aln_reader *r);
+void aln_device_rewind(aln_reader *r, size_t n);       /* the last n records handed out by aln_read_batch_device are handed out again (by whichever route reads next) */
 size_t aln_device_left(const aln_reader *r);  /* device decoder: records of the current window not yet taken */
 int aln_device_exhausted(aln_reader *r);
 void aln_readahead(aln_reader *r);            /* BAM: start decoding ahead of the first aln_read_batch */     /* device decoder: 1 when no record is left */

@@ -196,7 +196,9 @@ static void *warm_main(void *arg)
          * measured on 200 M reads: 8 windows 2.27 - 2.35 s per run, 48 windows 2.37 - 2.58 s. ITX_RESERVE_WINDOWS overrides. */
         {
             const char *we = getenv("ITX_RESERVE_WINDOWS");
-            const int ring = we && atol(we) >= 2 && atol(we) <= ITX_BAMWIN_WINDOWS ? (int)atol(we) : 2 * ITX_BAMWIN_LANES;
+            const char *pe = getenv("ITX_PUSHES");
+            const int lanes = pe && atoi(pe) >= 1 && atoi(pe) <= ITX_BAMWIN_LANES ? atoi(pe) : ITX_BAMWIN_LANES_DEFAULT;
+            const int ring = we && atol(we) >= 2 && atol(we) <= ITX_BAMWIN_WINDOWS ? (int)atol(we) : 2 * lanes;
             if (g_dev_windows < 1 || g_dev_windows > ring) g_dev_windows = ring;
         }
         const size_t max_bytes = max_blocks * 65280u < ((size_t)1 << 30) ? max_blocks * 65280u : (size_t)1 << 30;
@@ -261,6 +263,16 @@ static void gpu_warmup_join(void)
 static void chk(int rc, const char *what)
 {
     if (rc != ITX_OK) die("%s: %s", what, itx_last_error());
+}
+
+/* -R on the device: every window, right after its records are parsed (aln_set_window_hook) */
+static double t_dedup;
+static void dedup_window(void *ctx, size_t n_rec)
+{
+    (void)n_rec;
+    const double t0 = now_s();
+    chk(itx_bamwin_dedup(g_inflater, (itx_dedup *)ctx), "itx_bamwin_dedup");
+    t_dedup += now_s() - t0;
 }
 
 /* generic.c:781-791 (-C): NULL when the record is skipped ("GL*"), else the (possibly renamed) chromosome */
@@ -392,7 +404,8 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         iv = xcalloc(BATCH_RECORDS, sizeof *iv);
         live = xcalloc(BATCH_RECORDS, 1);
     }
-    dup_set *dups = o->dedup ? dup_set_new() : NULL;                   /* one set over all files, like `dup` (generic.c:721) */
+    itx_dedup *dd = NULL;
+    dup_set *dups = NULL;
     names_t chr_names;                                                 /* identities of the chromosome strings inside -R keys */
     names_init(&chr_names);
     xa_index *xi = NULL;
@@ -434,6 +447,16 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     gpu_warmup_join();
     if (timing) fprintf(stderr, "[itx timing] waited %.3f s for the helper thread\n", now_s() - t_join);
     if (g_inflater) use_device_reader();
+    /* -R: one set over all files, like `dup` (generic.c:721). BAM decoded on the device: the set lives there too
+     * (csrc/itx_dedup.hip) and marks a window's duplicates where the window lies, right after it is parsed; SAM text, the host
+     * decoder and ITX_HOST_DEDUP=1: the host's hash set, record by record */
+    if (o->dedup && g_inflater && !o->is_sam && !getenv("ITX_HOST_DEDUP")) {
+        size_t cells = warm_input_bytes / 24;                          /* a first guess at the keys to come; the table grows */
+        if (cells < ((size_t)1 << 20)) cells = (size_t)1 << 20;
+        if (cells > ((size_t)1 << 28)) cells = (size_t)1 << 28;
+        chk(itx_dedup_create(multi_device(), chr_sizes->value, (int)n_chrom, &p, cells, &dd), "itx_dedup_create");
+    }
+    dups = o->dedup && !dd ? dup_set_new() : NULL;
     if (shared && !g_inflater) die("rank %d: the device decoder did not come up: %s", rank, warm_err[0] ? warm_err : itx_last_error());
     /* pass 0: this rank's shares, then the exchange. pass 1 (rank 0 only, and only when a share boundary did not hold —
      * the split points are guesses that the rank before verifies): the whole job again by this rank alone */
@@ -481,11 +504,15 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                 const int64_t id = names_find(&chr_sizes->names, nm);
                 /* generic.c:796-797: cend = size-1 with 2 as the "not found" default; a listed size of 2 reads the same */
                 t2c[t] = (id >= 0 && (int)chr_sizes->value[id] != 2) ? (int32_t)id : -1;
-                if (dups) t2id[t] = names_intern(&chr_names, nm);
+                if (dups || dd) t2id[t] = names_intern(&chr_names, nm);
             }
         }
         chk(itx_engine_set_tidmap(eng, t2c, nt > 0 ? nt : 0), "itx_engine_set_tidmap");
         if (xv) chk(itx_xaveto_set_tidmap(xv, t2c, nt > 0 ? nt : 0), "itx_xaveto_set_tidmap");
+        if (dd) {
+            chk(itx_dedup_set_tidmap(dd, t2c, t2id, nt > 0 ? nt : 0), "itx_dedup_set_tidmap");
+            aln_set_window_hook(rd, dedup_window, dd);
+        }
         if (nt == 0) {
             /* no references: nothing can map; still count the read ends */
             int32_t none = -1;
@@ -504,10 +531,11 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                 const uint8_t *seen = NULL;
                 tq = now_s();
                 if (aln_device_window(rd, &wfl, &seen)) {
-                    /* a window with XA tags while the veto is on: the veto runs on the device too (itx_xaveto_*), as long as
-                     * the window is one batch; else, or when a record needs the host's reading, the host route as before */
+                    /* a window with XA tags while the veto is on: the veto runs on the device too (itx_xaveto_*), batch by batch
+                     * (a window of records without sequence holds several batches); when a record needs the host's reading, the
+                     * host route takes over from that batch on */
                     const int xa_window = veto_on && (wfl & 2);
-                    if (xa_window && (!dev_veto || aln_device_left(rd) > BATCH_RECORDS)) direct = 0;
+                    if (xa_window && !dev_veto) direct = 0;
                     for (int t = 0; t < nt && direct; t++)
                         if (seen[t] && t2c[t] == -1) direct = 0;
                     if (direct && xa_window && !xv) {
@@ -532,8 +560,9 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                                 chk(itx_engine_classify_device(eng, &db, n, itx_xaveto_hits(xv), itx_xaveto_stream(xv)), "itx_engine_classify_device");
                                 if (aln_device_xa_veto(rd, xv, n, &vetoed, &hard) != 0) die("device veto: %s", itx_last_error());
                                 t_host += now_s() - tv;
-                                if (hard) {                                       /* an alternative only strtol / the reference's assert can judge */
-                                    aln_device_rewind(rd);
+                                if (hard) {                                       /* an alternative only strtol / the reference's assert can judge: this batch
+                                                                                   * and the rest of the window take the host route (the batches before are through) */
+                                    aln_device_rewind(rd, n);
                                     direct = 0;
                                     tq = now_s();
                                     break;
@@ -607,7 +636,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             }
             /* ---- in file order: -R and the bed lines (generic.c:907-936) */
             int batch_xa = 0;
-            if (dups || bed_f || bed_uniq_f) {
+            if (dups || dd || bed_f || bed_uniq_f) {
                 for (size_t i = 0; i < n; i++) {
                     const int32_t t = st[s].tid[i];
                     const int32_t chrom = (t >= 0 && t < nt) ? t2c[t] : -1;
@@ -616,6 +645,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
                                      st[s].mpos[i], st[s].isize[i], &iv[i]))
                         continue;
                     const int uniq = st[s].mapq[i] >= o->mapq;
+                    if (dd && (st[s].flag5[i] & ITX_F5_NOLOOKUP)) continue;          /* a duplicate, marked on the device */
                     if (dups && dup_set_seen(dups, t2id[t], &iv[i], uniq)) {
                         st[s].flag5[i] |= ITX_F5_NOLOOKUP;
                         if (uniq && hc) hc->dup_unique++;
@@ -639,7 +669,7 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
 #pragma omp parallel for schedule(static)
                 for (long i = 0; i < (long)n; i++) {
                     live[i] = 0;
-                    if (!side[s].xa[i]) continue;
+                    if (!side[s].xa[i] || (st[s].flag5[i] & ITX_F5_NOLOOKUP)) continue;
                     const int32_t t = st[s].tid[i];
                     const int32_t chrom = (t >= 0 && t < nt) ? t2c[t] : -1;
                     live[i] = (uint8_t)host_derive(o, chrom, chrom >= 0 ? chr_sizes->value[chrom] : 0, st[s].flag5[i], st[s].pos[i],
@@ -793,6 +823,14 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     if (bed_f) fclose(bed_f);
     if (bed_uniq_f) fclose(bed_uniq_f);
     dup_set_free(dups);
+    if (dd) {
+        uint64_t du = 0, dropped = 0, keys = 0;
+        chk(itx_dedup_counts(dd, &du, &dropped, &keys), "itx_dedup_counts");
+        if (hc) hc->dup_unique = du;
+        if (timing) fprintf(stderr, "[itx timing] -R on the device: %llu records dropped (%llu of them MAPQ >= -Q), %llu keys, %.3f s in its kernels\n",
+                            (unsigned long long)dropped, (unsigned long long)du, (unsigned long long)keys, t_dedup);
+        itx_dedup_destroy(dd);
+    }
     xa_index_free(xi);
     itx_xaveto_destroy(xv);
     free(iv);

@@ -47,15 +47,17 @@ def big():
 
 @pytest.fixture(scope="module")
 def files(big, tmp_path_factory):
-    """the table as files + BAMs from tools/mkbam.c (no SEQ/QUAL: the reference's time goes into its scan either way)"""
+    """the table as files + BAMs from tools/mkbam.c: the 50 M-read one (both programs read it) carries 50 bases + 40-value qualities
+    per record, independent bases, Illumina-style names and 5 % CIGARs with S / D / I / N — what a BAM looks like to a DEFLATE
+    decoder and to bam_calend; the 500 M-read one (chunking of the command alone) carries none"""
     wd = str(tmp_path_factory.mktemp("scale"))
     subprocess.check_call(["gcc", "-O2", "-fopenmp", "-o", MKBAM, os.path.join(ROOT, "tools", "mkbam.c"), "-lz", "-ldl"])
     synth.write_sizes(os.path.join(wd, "chrom.sizes"), big["chroms"])
     synth.write_sizes(os.path.join(wd, "rep.sizes"), big["tb"].rep_len.items())
     synth.write_rmsk(os.path.join(wd, "rmsk.txt"), big["tb"], workers=int(THREADS))
     env = dict(os.environ, OMP_NUM_THREADS=THREADS)
-    for name, n in (("r50M.bam", 50_000_000), ("r500M.bam", 500_000_000)):
-        subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(n), os.path.join(wd, name), "0", "11"], env=env)
+    subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), "50000000", os.path.join(wd, "r50M.bam"), "50", "11", "0", "content=hiseq", "cigar=mixed"], env=env)
+    subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), "500000000", os.path.join(wd, "r500M.bam"), "0", "11"], env=env)
     return wd
 
 

@@ -6,7 +6,10 @@
      as a child process, before anything touches the GPU; under torch.distributed.run it is one rank per GPU.)
 
 Workload, N = 1 (BASELINE.json configs[2]): a coordinate-sorted 500 M-read synthetic hg38 BAM whose records carry 100 bases
-+ qualities (tools/mkbam.c: BGZF level 1, ~46 B/read compressed, ~200 B/read inflated) against a 5.5 M-row
++ qualities (tools/mkbam.c, BGZF level 1) with the CONTENT of a sequencer's BAM — `--content hiseq` (the default): independent
+bases, 40-value qualities, Illumina-style names, 5 % CIGARs with S / D / I / N: ~112 B/read compressed, ~220 B/read inflated,
+23 k literals + 7 k matches per BGZF block (stated in `config.content`, counted from the file) — `--content legacy` is round 2's
+file, 97 % of whose bytes come out of LZ77 matches — against a 5.5 M-row
 RepeatMasker-like table (15 k names / 60 families / 20 classes), `iteres stat -w` with the reference's defaults
 (-Q 10 -E 150 -c 1e-4), per-base coverage wigs kept. One "step" = ONE whole run of the command
 (iteres_amd/host/iteres: size files + rmsk parse -> table build -> BAM decode on the device -> overlap classification +
@@ -18,11 +21,16 @@ process per GPU) take equal shares of the list's compressed bytes, every rank ho
 accumulators, and ONE sum-reduce (RCCL over xGMI) of the compact partial onto rank 0 ends the stream; rank 0 writes the
 files. `strong_scaling` in the same line: the ONE 500 M-read BAM split N ways.
 
+`filter_leg` (configs[4]): `iteres filter -c <the biggest class>` end to end on the same BAM, the reference on the sample beside
+it, and the HIP-event time of k_stream<ATOMIC_LOCUS> on the resident records. `cpu_baseline_mt`: our CPU restatement (the
+oracle) on the 16 cores of the box's CPU share — the hot path only.
+
 `roofline`: the overlap kernel k_stream (derive + classify + key emit) on the same number of records RESIDENT in HBM,
 timed with HIP events on the submitting stream around every launch; bytes counted both ways (SURVEY.md §8(d) K1 bytes
 = `achieved`/`frac`; the as-built movement = `as_built`). `cpu_baseline` (rank 0, N = 1): the REFERENCE binary
 (oracle/_ref/iteres, compiled from the reference's own sources — test infrastructure) on a bounded prefix-sized sample
-of the same workload; every text output of the two programs on that sample is compared byte for byte.
+of the same workload (median of 3 runs; the same sources at -O2 beside it); every text output of the two programs on that sample
+is compared byte for byte.
 """
 from __future__ import annotations
 
@@ -75,7 +83,9 @@ def parse_args():
     ap.add_argument("--threads", type=int, default=0, help="host threads of the command (0: min(16, cores))")
     ap.add_argument("--workdir", default=os.environ.get("ITX_BENCH_DIR", ""))
     ap.add_argument("--keep", action="store_true", help="keep the generated inputs (they are reused when present)")
-    ap.add_argument("--no-settle", action="store_true", help="skip the device-memory warm-up (see vram_settle)")
+    ap.add_argument("--settle", action="store_true", help="take and release most of the card once before anything is timed (see vram_settle; round 2's default, "
+                    "when the command reserved 50 GB per run — it reserves 12 GB now and the warm-up runs see to those)")
+    ap.add_argument("--no-settle", action="store_true", help="(the default now; kept for old command lines)")
     ap.add_argument("--no-replay-check", action="store_true", help="profiling runs: skip the small oracle-checked launch, so that every k_stream launch of this process has the replay's size")
     return ap.parse_args()
 
@@ -124,7 +134,7 @@ def ensure_inputs(a, threads):
     """chrom.sizes / rep.sizes / rmsk.txt / reads.bam / sample.bam for these parameters, generated once per box."""
     from iteres_amd import synth
     mkopts = mkbam_options(a)
-    key = f"r{a.reads}_s{a.seq_len}_t{a.rows}_c{a.cpu_reads}_" + "_".join(o.split("=")[1] for o in mkopts)
+    key = f"r{a.reads}_s{a.seq_len}_t{a.rows}_c{a.cpu_reads if getattr(a, 'gpus', 1) == 1 else 0}_" + "_".join(o.split("=")[1] for o in mkopts)
     wd = a.workdir or os.path.join("/tmp", f"itx_bench_{key}")
     os.makedirs(wd, exist_ok=True)
     done = os.path.join(wd, "inputs.json")
@@ -141,7 +151,7 @@ def ensure_inputs(a, threads):
     t1 = time.time()
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.reads), os.path.join(wd, "reads.bam"), str(a.seq_len), "7"] + mkopts, env=env)
-    if a.cpu_reads > 0:
+    if a.cpu_reads > 0 and getattr(a, 'gpus', 1) == 1:
         subprocess.check_call([MKBAM, os.path.join(wd, "chrom.sizes"), str(a.cpu_reads), os.path.join(wd, "sample.bam"), str(a.seq_len), "7"] + mkopts, env=env)
     info = {"table_s": round(t1 - t0, 1), "bam_s": round(time.time() - t1, 1), "bam_bytes": os.path.getsize(os.path.join(wd, "reads.bam")),
             "n_rep": len(tb.names), "n_fam": len(tb.fams), "n_cla": len(tb.clas)}
@@ -414,7 +424,7 @@ def main():
             torch.cuda.synchronize()
 
     # ---------------------------------------------------------------- device memory settled before anything is timed
-    settle = None if a.no_settle or os.environ.get("ITX_BENCH_SHARE_GPU") == "1" else vram_settle(local_rank)      # (ranks sharing one card would fight over it)
+    settle = vram_settle(local_rank) if a.settle and os.environ.get("ITX_BENCH_SHARE_GPU") != "1" else None      # (ranks sharing one card would fight over it)
 
     # ---------------------------------------------------------------- inputs: rank 0 makes them, everybody learns where
     box = [None, None]

@@ -244,7 +244,7 @@ int itx_engine_get_stats(itx_engine *e, itx_stats *out);
  * the caller's zlib has the last word, as in the reference). Synchronous; one calling thread per inflater. */
 typedef struct itx_inflater itx_inflater;
 #define ITX_BAMWIN_LANES 8        /* pushes that may be in flight at once (push_begin's s); ITX_PUSHES (environment) says how many an inflater sets up */
-#define ITX_BAMWIN_LANES_DEFAULT 4
+#define ITX_BAMWIN_LANES_DEFAULT 8  /* their kernels share ITX_LANES (default 4) compute lanes: the next push's bytes cross PCIe while a lane computes */
 #define ITX_BAMWIN_WINDOWS 48     /* windows of inflated bytes (w): the decode may run this far ahead of the consumer (a window's
                                    * buffer is allocated when it is first pushed into: 288 GB of HBM is room for a long lead) */
 typedef struct itx_bgzf_block {

@@ -323,7 +323,8 @@ __global__ void k_warm(uint32_t *p)
 
 static void report_at_exit();
 
-// lanes an inflater sets up (streams, events, reserved scratch): ITX_PUSHES, 1 .. ITX_BAMWIN_LANES
+// pushes an inflater can hold in flight (a SLOT each: copy stream, events, compressed bytes, block list, status): ITX_PUSHES,
+// 1 .. ITX_BAMWIN_LANES
 static int lanes_in_use()
 {
     static int v;
@@ -331,6 +332,23 @@ static int lanes_in_use()
         const char *e = getenv("ITX_PUSHES");
         const int x = e ? atoi(e) : 0;
         v = x >= 1 && x <= ITX_BAMWIN_LANES ? x : ITX_BAMWIN_LANES_DEFAULT;
+    }
+    return v;
+}
+// ... and the COMPUTE lanes their kernels run on (a stream and the 88 KB of token scratch per block each): ITX_LANES, at most
+// the slots. Slot s computes on lane s % n. A push used to copy and compute on one stream: a lane was busy copy + pass 1 + pass 2
+// = 46 ms per push of which the kernels are 34 — on average 2.6 of 4 pass-1 kernels were running (profiles/r03_cli_500M_trace_*).
+// With more slots than lanes the next push's bytes cross PCIe while the lane still computes; more LANES instead cost a gigabyte
+// of scratch each and their kernels crowd the engine's out of the CUs (k_hist 0.67 -> 3.1 ms with 8).
+#define ITX_COMPUTE_LANES_DEFAULT 4
+static int compute_lanes()
+{
+    static int v;
+    if (!v) {
+        const char *e = getenv("ITX_LANES");
+        const int x = e ? atoi(e) : 0;
+        v = x >= 1 && x <= ITX_BAMWIN_LANES ? x : ITX_COMPUTE_LANES_DEFAULT;
+        if (v > lanes_in_use()) v = lanes_in_use();
     }
     return v;
 }
@@ -355,18 +373,24 @@ struct itx_inflater {
         uint32_t start, len, consumed;     // unconsumed bytes are buf[start, len); consumed: end of the last parsed record
     } win[ITX_BAMWIN_WINDOWS];
     // a push in flight: its own stream and scratch, so that the Huffman pass of one chunk runs beside the replay of the last
+    hipStream_t copy_st;
     struct {
-        hipStream_t st;
         hipEvent_t copied;                 // the compressed bytes have left the caller's buffer
         hipEvent_t ev[3];                  // ITX_TIMING: before pass 1, between the passes, after pass 2
         hipEvent_t p1_done, done;          // pass 1 through (the shared pass-2 stream waits for it); the whole push through
-        uint8_t *d_comp, *d_status, *d_lit, *h_status;
-        uint32_t *d_meta;
+        uint8_t *d_comp, *d_status, *h_status;
         itx_bgzf_block *d_blk, *h_blk;     // h_blk (page-locked): the block list shifted to the window's offsets
-        size_t comp_cap, status_cap, lit_cap, meta_cap, blk_cap, h_cap;
+        size_t comp_cap, status_cap, blk_cap, h_cap;
         size_t n_blk, total;
         int busy;
     } lane[ITX_BAMWIN_LANES];
+    // a compute lane: the stream the two passes of its slots' pushes run on, one after the other, and their scratch
+    struct {
+        hipStream_t cst;
+        uint8_t *d_lit;
+        uint32_t *d_meta;
+        size_t lit_cap, meta_cap;
+    } clane[ITX_BAMWIN_LANES];
     void *d_sum, *h_sum;                   // PieceSum per piece, and its host copy
     uint32_t *d_spec, *d_pb, *h_pb, *d_recoff, *d_flags;
     uint8_t *d_seen;
@@ -412,12 +436,16 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     for (int k = 0; k < 4; k++) INF_HIP(hipEventCreate(&h->ev[k]));
     for (int k = 0; k < 2; k++) INF_HIP(hipEventCreate(&h->ev_res_end[k]));
     for (int k = 0; k < lanes_in_use(); k++) {
-        INF_HIP(hipStreamCreateWithFlags(&h->lane[k].st, hipStreamNonBlocking));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].copied, hipEventDisableTiming));
         for (int q = 0; q < 3; q++) INF_HIP(hipEventCreate(&h->lane[k].ev[q]));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].p1_done, hipEventDisableTiming));
         INF_HIP(hipEventCreateWithFlags(&h->lane[k].done, hipEventDisableTiming));
     }
+    // ONE stream carries every push's bytes across PCIe, in push order (the link is one: copies side by side only finish later,
+    // all of them); a stream per slot also meant more streams than hardware queues, and streams that share a queue run one
+    // after the other — two compute lanes on one queue halved pass 1's overlap (1.8 kernels in flight instead of 3)
+    INF_HIP(hipStreamCreateWithFlags(&h->copy_st, hipStreamNonBlocking));
+    for (int k = 0; k < compute_lanes(); k++) INF_HIP(hipStreamCreateWithFlags(&h->clane[k].cst, hipStreamNonBlocking));
     SETUP_TICK("lane streams, events, counters");
     h->n_cu = 256;
     if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
@@ -454,24 +482,28 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     (void)hipFree(h->d_meta);
     for (int k = h->arena ? h->n_reserved_win : 0; k < ITX_BAMWIN_WINDOWS; k++) (void)hipFree(h->win[k].buf);
     for (int k = 0; k < ITX_BAMWIN_LANES; k++) {
-        if (h->lane[k].st) {
-            (void)hipStreamSynchronize(h->lane[k].st);
-            (void)hipStreamDestroy(h->lane[k].st);
-        }
         if (h->lane[k].copied) (void)hipEventDestroy(h->lane[k].copied);
         for (int q = 0; q < 3; q++)
             if (h->lane[k].ev[q]) (void)hipEventDestroy(h->lane[k].ev[q]);
         if (h->lane[k].p1_done) (void)hipEventDestroy(h->lane[k].p1_done);
         if (h->lane[k].done) (void)hipEventDestroy(h->lane[k].done);
+        if (h->clane[k].cst) {
+            (void)hipStreamSynchronize(h->clane[k].cst);
+            (void)hipStreamDestroy(h->clane[k].cst);
+        }
         if (!h->arena) {
             (void)hipFree(h->lane[k].d_comp);
             (void)hipFree(h->lane[k].d_status);
-            (void)hipFree(h->lane[k].d_lit);
-            (void)hipFree(h->lane[k].d_meta);
+            (void)hipFree(h->clane[k].d_lit);
+            (void)hipFree(h->clane[k].d_meta);
             (void)hipFree(h->lane[k].d_blk);
         }
         if (h->lane[k].h_blk) (void)hipHostFree(h->lane[k].h_blk);
         if (h->lane[k].h_status) (void)hipHostFree(h->lane[k].h_status);
+    }
+    if (h->copy_st) {
+        (void)hipStreamSynchronize(h->copy_st);
+        (void)hipStreamDestroy(h->copy_st);
     }
     (void)hipFree(h->arena);
     (void)hipFree(h->d_sum);
@@ -687,23 +719,27 @@ extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *
         Ln.h_blk[i] = blk[i];
         Ln.h_blk[i].uoff += WIN_HEAD;
     }
+    auto &CL = h->clane[s % compute_lanes()];
     if ((rc = grow(&Ln.d_comp, &Ln.comp_cap, comp_len + 64)) != ITX_OK) return rc;
     if ((rc = grow(&Ln.d_status, &Ln.status_cap, n_blk)) != ITX_OK) return rc;
     if ((rc = grow(&Ln.d_blk, &Ln.blk_cap, n_blk)) != ITX_OK) return rc;
-    if ((rc = grow(&Ln.d_lit, &Ln.lit_cap, n_blk * (size_t)SCR_STRIDE)) != ITX_OK) return rc;
-    if ((rc = grow(&Ln.d_meta, &Ln.meta_cap, 3 * n_blk)) != ITX_OK) return rc;
-    hipStream_t st = Ln.st;
-    INF_HIP(hipMemcpyAsync(Ln.d_blk, Ln.h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, st));
-    INF_HIP(hipMemcpyAsync(Ln.d_comp, comp, comp_len, hipMemcpyHostToDevice, st));
-    INF_HIP(hipEventRecord(Ln.copied, st));
+    if ((rc = grow(&CL.d_lit, &CL.lit_cap, n_blk * (size_t)SCR_STRIDE)) != ITX_OK) return rc;      // (growing frees: that waits for whatever still runs)
+    if ((rc = grow(&CL.d_meta, &CL.meta_cap, 3 * n_blk)) != ITX_OK) return rc;
+    // the bytes cross PCIe on the copy stream ...
+    INF_HIP(hipMemcpyAsync(Ln.d_blk, Ln.h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, h->copy_st));
+    INF_HIP(hipMemcpyAsync(Ln.d_comp, comp, comp_len, hipMemcpyHostToDevice, h->copy_st));
+    INF_HIP(hipEventRecord(Ln.copied, h->copy_st));
+    // ... and both passes run on the compute lane, behind the push that had the lane (and its scratch) before
+    hipStream_t st = CL.cst;
+    INF_HIP(hipStreamWaitEvent(st, Ln.copied, 0));
     INF_HIP(hipEventRecord(Ln.ev[0], st));
-    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, Ln.d_lit, Ln.d_meta);
+    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, CL.d_lit, CL.d_meta);
     INF_HIP(hipGetLastError());
-    // pass 2 on the push's own stream, one wave per block (every push's pass 2 on one shared stream, or a fixed set of waves
+    // pass 2 on the same stream, one wave per block (every push's pass 2 on one shared stream, or a fixed set of waves
     // that take blocks in turn, were measured slower: DESIGN.md)
     hipStream_t sr = st;
     INF_HIP(hipEventRecord(Ln.ev[1], sr));
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, sr, Ln.d_blk, 0u, (uint32_t)n_blk, Ln.d_lit, Ln.d_meta, h->win[w].buf, Ln.d_status);
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, sr, Ln.d_blk, 0u, (uint32_t)n_blk, CL.d_lit, CL.d_meta, h->win[w].buf, Ln.d_status);
     INF_HIP(hipGetLastError());
     INF_HIP(hipEventRecord(Ln.ev[2], sr));
     INF_HIP(hipMemcpyAsync(Ln.h_status, Ln.d_status, n_blk, hipMemcpyDeviceToHost, sr));
@@ -729,7 +765,6 @@ extern "C" int itx_bamwin_push_end(itx_inflater *h, int s, uint8_t *status, size
     if (!Ln.busy) return ITX_E_STATE;
     INF_HIP(hipSetDevice(h->device));
     if (Ln.n_blk) INF_HIP(hipEventSynchronize(Ln.done));
-    else INF_HIP(hipStreamSynchronize(Ln.st));
     if (Ln.n_blk) {
         float a = 0, b = 0;
         if (hipEventElapsedTime(&a, Ln.ev[0], Ln.ev[1]) == hipSuccess && hipEventElapsedTime(&b, Ln.ev[1], Ln.ev[2]) == hipSuccess) {
@@ -771,8 +806,8 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t sz_comp = al(comp_bytes + 64), sz_status = al(max_blocks), sz_blk = al(max_blocks * sizeof(itx_bgzf_block)), sz_lit = al(max_blocks * (size_t)SCR_STRIDE),
                  sz_meta = al(3 * max_blocks * 4);
-    const size_t lane_bytes = sz_comp + sz_status + sz_blk + sz_lit + sz_meta;
-    const size_t total = lane_bytes * (size_t)n_lanes + per * n;
+    const int n_comp = compute_lanes();
+    const size_t total = (sz_comp + sz_status + sz_blk) * (size_t)n_lanes + (sz_lit + sz_meta) * (size_t)n_comp + per * n;
     uint8_t *base = nullptr;
     const double t0 = wall_now();
     hipError_t he = hipMalloc((void **)&base, total);
@@ -790,8 +825,6 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
         Ln.d_comp = p; p += sz_comp; Ln.comp_cap = comp_bytes + 64;
         Ln.d_status = p; p += sz_status; Ln.status_cap = max_blocks;
         Ln.d_blk = (itx_bgzf_block *)p; p += sz_blk; Ln.blk_cap = max_blocks;
-        Ln.d_lit = p; p += sz_lit; Ln.lit_cap = max_blocks * (size_t)SCR_STRIDE;
-        Ln.d_meta = (uint32_t *)p; p += sz_meta; Ln.meta_cap = 3 * max_blocks;
         if (Ln.h_cap < max_blocks) {
             if (Ln.h_blk) (void)hipHostFree(Ln.h_blk);
             if (Ln.h_status) (void)hipHostFree(Ln.h_status);
@@ -802,6 +835,11 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
             INF_HIP(hipHostMalloc((void **)&Ln.h_status, max_blocks + 64, hipHostMallocDefault));
             Ln.h_cap = max_blocks + 64;
         }
+    }
+    for (int k = 0; k < n_comp; k++) {
+        auto &CL = h->clane[k];
+        CL.d_lit = p; p += sz_lit; CL.lit_cap = max_blocks * (size_t)SCR_STRIDE;
+        CL.d_meta = (uint32_t *)p; p += sz_meta; CL.meta_cap = 3 * max_blocks;
     }
     for (size_t w = 0; w < n; w++) {
         if (h->win[w].buf) (void)hipFree(h->win[w].buf);

@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -60,6 +62,8 @@ struct aln_reader {
     int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
     size_t io_off, io_size;
     size_t raw_step;          /* bytes per read step (aln_raw_step) */
+    uint8_t *map;             /* the device decoder on a regular file: the whole file mapped read-only (cbuf points into it) */
+    size_t map_len;
     void (*win_hook)(void *, size_t);   /* aln_set_window_hook */
     void *win_hook_ctx;
     int io_on, io_stop, io_done; /* io_done: the file is read out and its last chunk taken */
@@ -538,6 +542,25 @@ static size_t raw_next(aln_reader *r)
             if (r->dev && r->io_fd >= 0 && dev.push_copied) r->n_raw = N_RAW_DEVICE_FILE;
         }
         r->raw_step = r->io_fd >= 0 ? aln_raw_step(r->io_size > r->io_off ? r->io_size - r->io_off : 0) : RAW_STEP;
+        /* ITX_MMAP=1 (an experiment that lost, kept for the record): the file is MAPPED and the device copies a chunk's bytes
+         * straight out of the page cache, which would save the 11 core-seconds the eight pread threads spend per 56 GB — of the
+         * 16 cores a GPU's share of the box has. A plain hipMemcpy from a read-only mapping does run at 55 GB/s
+         * (profiles/r03_mmap_probe.txt), and the table build beside it takes 0.19 - 0.34 s instead of 0.45 - 0.85; but the
+         * asynchronous copies of the pipeline go through the runtime's staging path in pieces (2027 copies for 139 pushes) and
+         * hold the producer thread, and tearing down the page tables of 56 GB of touched mapping costs 0.58 s at close:
+         * 4.0 - 4.1 s per run against 3.2 - 3.8 s (profiles/r03_cli_500M_hiseq_mmap.json). */
+        if (r->n_raw == N_RAW_DEVICE_FILE && getenv("ITX_MMAP") && r->io_size > 0) {
+            void *m = mmap(NULL, r->io_size, PROT_READ, MAP_SHARED, r->io_fd, 0);
+            if (m != MAP_FAILED) {
+                r->map = m;
+                r->map_len = r->io_size;
+                (void)madvise(m, r->io_size, MADV_SEQUENTIAL);
+                r->cbuf = r->map + r->io_off;
+                r->clen = 0;
+                r->io_on = 2;                                       /* no reader thread */
+            }
+        }
+        if (r->map) goto mapped;
         pthread_mutex_init(&r->io_mu, NULL);
         pthread_cond_init(&r->io_cv, NULL);
         r->io_fill = r->io_take = 0;
@@ -545,6 +568,19 @@ static size_t raw_next(aln_reader *r)
         r->io_stop = 0;
         if (pthread_create(&r->io_thread, NULL, io_main, r) != 0) die("cannot start the file read-ahead thread");
         r->io_on = 1;
+    }
+    if (r->map) {
+    mapped:;
+        /* the next step's bytes are simply there, behind what the indexer left over (no carry: the file is one piece) */
+        size_t got = r->io_size > r->io_off ? r->io_size - r->io_off : 0;
+        if (got > r->raw_step) got = r->raw_step;
+        r->io_off += got;
+        r->clen += got;
+        r->io_abs_end += got;
+        if (got < r->raw_step) r->io_done = 1;
+        /* a file that is not in the page cache: ask for the chunks to come while this one is decoded */
+        if (!r->io_done) (void)posix_fadvise(r->io_fd, (off_t)r->io_off, (off_t)(2 * r->raw_step), POSIX_FADV_WILLNEED);
+        return got;
     }
     pthread_mutex_lock(&r->io_mu);
     while (r->io_fill <= r->io_take) pthread_cond_wait(&r->io_cv, &r->io_mu);
@@ -745,7 +781,7 @@ static void dev_begin(aln_reader *r)
     j->nb = nb_use;
     j->cbase = r->cbuf;
     j->cabs = r->io_fd >= 0 ? r->io_abs_end - r->clen : SIZE_MAX;
-    if (r->n_raw == N_RAW_DEVICE_FILE && r->io_on) {
+    if (r->n_raw == N_RAW_DEVICE_FILE && r->io_on == 1) {
         pthread_mutex_lock(&r->io_mu);
         r->raw_lanes[r->raw_cur] |= 1u << (k % pushes_in_flight());
         pthread_mutex_unlock(&r->io_mu);
@@ -1156,12 +1192,29 @@ aln_reader *aln_open(const char *path, int is_sam)
                 DEV_CHK(dev.avail(dev.ctx, w, &left), "avail");
                 DEV_CHK(dev.skip(dev.ctx, w, left), "skip");
             }
-        rc = bam_read_header(r);
-        if (r->dev && rc == 0) {
-            DEV_CHK(dev.skip(dev.ctx, r->dw, r->hdr_pos), "skip");                 /* the records start here */
-            free(r->hdr);
-            r->hdr = NULL;
-            r->hdr_len = r->hdr_pos = 0;
+        struct stat sb;
+        if (r->dev && !getenv("ITX_HEADER_BY_DEVICE") && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode)) {
+            /* a regular file: the reference list by the plain host reader (a few blocks, milliseconds), and the device's stream
+             * skips that many bytes when its first window arrives. Reading the header through the device meant one whole push —
+             * a chunk read, copied and decoded while nothing else ran (0.19 s) — before the pipeline of pushes could start. */
+            hz_t z;
+            memset(&z, 0, sizeof z);
+            z.fd = fileno(f);
+            z.size = (size_t)sb.st_size;
+            r->hz = &z;
+            rc = bam_read_header(r);
+            r->hz = NULL;
+            r->dskip_left = z.pos;
+            hz_free(&z);
+            r->dparsed = 1;                                        /* nothing to parse before the first window is in */
+        } else {
+            rc = bam_read_header(r);
+            if (r->dev && rc == 0) {
+                DEV_CHK(dev.skip(dev.ctx, r->dw, r->hdr_pos), "skip");             /* the records start here */
+                free(r->hdr);
+                r->hdr = NULL;
+                r->hdr_len = r->hdr_pos = 0;
+            }
         }
     }
     if (rc != 0) {
@@ -1315,7 +1368,8 @@ void aln_close(aln_reader *r)
             dev_end(r);
             r->dk_ready++;
         }
-    if (r->io_on) {
+    if (r->map) munmap(r->map, r->map_len);                                    /* (every push has ended: nothing copies out of it any more) */
+    if (r->io_on == 1) {
         pthread_mutex_lock(&r->io_mu);
         r->io_stop = 1;                                                        /* (a read in flight lands first: the thread looks when it is back) */
         pthread_cond_broadcast(&r->io_cv);

@@ -29,13 +29,11 @@ int main(int argc, char *argv[])
     struct timespec ts_main0;
     clock_gettime(CLOCK_MONOTONIC, &ts_main0);
     /* The HIP runtime multiplexes its streams onto 4 hardware queues by default, and kernels that share a hardware queue run
-     * one after the other. The decoder keeps four pushes in flight on streams of their own next to the engine's: with 8 queues
-     * their kernels really do overlap (measured: scan of the 500 M-read BAM 1.95 s instead of 2.3 s). Read by the runtime when it
-     * starts, so it has to be in the environment before the first HIP call; a value the user set stays. */
-    {
-        const char *pe = getenv("ITX_PUSHES");
-        setenv("GPU_MAX_HW_QUEUES", pe && atoi(pe) > 4 ? "12" : "8", 0);
-    }
+     * one after the other. The decoder computes on four lanes of its own next to the engine's stream, and eight copy streams feed
+     * them: with enough queues their kernels really do overlap (measured in round 2 with 8: scan of the 500 M-read BAM 1.95 s
+     * instead of 2.3 s). Read by the runtime when it starts, so it has to be in the environment before the first HIP call; a
+     * value the user set stays. */
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
     multi_early(argc, argv);
     /* host threads (BGZF inflate, record parse, bigWig deflate): OMP_NUM_THREADS when given, else the processors this
      * process may run on, capped — the decode saturates long before a big host's core count and idle OpenMP workers

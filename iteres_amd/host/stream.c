@@ -49,7 +49,22 @@ static void *pool_alloc(size_t n)
         if (pool[i].p && !pool[i].used && pool[i].cap >= n && (best < 0 || pool[i].cap < pool[best].cap)) best = i;
     if (best >= 0) pool[best].used = 1;
     pthread_mutex_unlock(&pool_mu);
-    return best >= 0 ? pool[best].p : itx_pinned_alloc(n);
+    if (best >= 0) return pool[best].p;
+    /* a fresh one joins the pool when there is a place: released, it stays locked (for the next file; unlocking 384 MB takes
+     * 30 ms, and at the end of the run the process leaves without) */
+    void *p = itx_pinned_alloc(n);
+    if (p) {
+        pthread_mutex_lock(&pool_mu);
+        for (int i = 0; i < POOL_N; i++)
+            if (!pool[i].p) {
+                pool[i].p = p;
+                pool[i].cap = n;
+                pool[i].used = 1;
+                break;
+            }
+        pthread_mutex_unlock(&pool_mu);
+    }
+    return p;
 }
 static void pool_release(void *p)
 {
@@ -144,6 +159,17 @@ static void *early_comm_main(void *arg)
     return NULL;
 }
 
+static size_t pin_want;
+static void *pin_main(void *arg)
+{
+    (void)arg;
+    for (int i = 0; i < 2 && i < POOL_N; i++) {
+        pool[i].p = itx_pinned_alloc(pin_want);
+        pool[i].cap = pool[i].p ? pin_want : 0;
+    }
+    return NULL;
+}
+
 static void *warm_main(void *arg)
 {
     (void)arg;
@@ -155,27 +181,32 @@ static void *warm_main(void *arg)
         early_comm.on = 1;
     double t_created = b, t_pinned = b;
     int inf_rc = ITX_OK;
+    /* the compressed chunks the reader rotates through are page-locked, which takes its time (0.1 - 0.2 s for the first two): a
+     * thread of its own locks them while this one makes the inflater's streams; the others are locked by the reader thread when
+     * it first needs them, beside the device's work */
+    const char *ce = getenv("ITX_BGZF_CHUNK");
+    const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
+    size_t step = chunk;
+    pthread_t pin_th;
+    int pin_on = 0;
+    if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE")) {
+        use_device_reader();                                             /* (aln_raw_step asks which decoder is in use; the inflater itself follows) */
+        /* what the reader will ask for: a step's bytes plus room for a carried-over block; a small input gets small buffers */
+        const size_t mine_bytes = warm_input_bytes ? warm_input_bytes / (size_t)(multi_world() > 0 ? multi_world() : 1) : 0;
+        step = mine_bytes && !ce ? aln_raw_step(mine_bytes + mine_bytes / 64) : chunk;
+        pin_want = step + (1u << 17);
+        pin_on = pthread_create(&pin_th, NULL, pin_main, NULL) == 0;
+    }
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && (inf_rc = itx_inflater_create(multi_device(), &g_inflater)) != ITX_OK)
         snprintf(warm_err, sizeof warm_err, "%s", itx_last_error());
     else if (ndev <= 0)
         snprintf(warm_err, sizeof warm_err, "no usable GPU (%s)", itx_last_error());
+    t_created = now_s();
+    if (pin_on) pthread_join(pin_th, NULL);
+    else if (g_inflater) pin_main(NULL);
+    t_pinned = now_s();
+    if (!g_inflater) aln_use_device(NULL);                              /* it did not come up: the host decodes (run_stream says why when that will not do) */
     if (g_inflater) {
-        t_created = now_s();
-        /* the compressed chunks the reader rotates through (one being read, the others being decoded) */
-        const char *ce = getenv("ITX_BGZF_CHUNK");
-        const size_t chunk = ce && atol(ce) >= 1 ? (size_t)atol(ce) : ALN_DEVICE_CHUNK;
-        size_t want[POOL_N];
-        use_device_reader();                                             /* (aln_raw_step asks which decoder is in use) */
-        /* what the reader will ask for: a step's bytes plus room for a carried-over block; a small input gets small buffers */
-        const size_t mine_bytes = warm_input_bytes ? warm_input_bytes / (size_t)(multi_world() > 0 ? multi_world() : 1) : 0;
-        const size_t step = mine_bytes && !ce ? aln_raw_step(mine_bytes + mine_bytes / 64) : chunk;
-        for (int i = 0; i < POOL_N; i++) want[i] = step + (1u << 17);
-        /* the first two now; the third is locked by the producer thread when it first needs it, beside the device's work */
-        for (int i = 0; i < 2 && i < POOL_N; i++) {
-            pool[i].p = itx_pinned_alloc(want[i]);
-            pool[i].cap = pool[i].p ? want[i] : 0;
-        }
-        t_pinned = now_s();
         /* the device side of the decoder, all of it, now that nothing runs there yet: windows and per-push scratch sized for
          * the most a push may carry (the block indexer cuts a chunk that inflates to more into two pushes) */
         const char *be = getenv("ITX_DEV_WINDOW_BLOCKS");
@@ -190,7 +221,7 @@ static void *warm_main(void *arg)
             const size_t nchunks = mine / chunk + 3;
             if (nchunks < ITX_BAMWIN_WINDOWS) g_dev_windows = (int)nchunks;          /* in: the most this input can use */
         }
-        /* The ring the pushes rotate through: the pushes in flight plus as many windows again for the consumer. A deeper ring
+        /* The ring the pushes rotate through: the pushes in flight plus four windows for the consumer. A deeper ring
          * (round 2: up to 48 windows, 50 GB of HBM for a 23 GB file) only let the decoder run ahead while the table was still
          * being built, and paid for it in device allocation time — seconds on a box whose memory the driver had yet to clear;
          * measured on 200 M reads: 8 windows 2.27 - 2.35 s per run, 48 windows 2.37 - 2.58 s. ITX_RESERVE_WINDOWS overrides. */
@@ -198,7 +229,7 @@ static void *warm_main(void *arg)
             const char *we = getenv("ITX_RESERVE_WINDOWS");
             const char *pe = getenv("ITX_PUSHES");
             const int lanes = pe && atoi(pe) >= 1 && atoi(pe) <= ITX_BAMWIN_LANES ? atoi(pe) : ITX_BAMWIN_LANES_DEFAULT;
-            const int ring = we && atol(we) >= 2 && atol(we) <= ITX_BAMWIN_WINDOWS ? (int)atol(we) : 2 * lanes;
+            const int ring = we && atol(we) >= 2 && atol(we) <= ITX_BAMWIN_WINDOWS ? (int)atol(we) : lanes + 4;
             if (g_dev_windows < 1 || g_dev_windows > ring) g_dev_windows = ring;
         }
         const size_t max_bytes = max_blocks * 65280u < ((size_t)1 << 30) ? max_blocks * 65280u : (size_t)1 << 30;

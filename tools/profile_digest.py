@@ -37,18 +37,28 @@ if best:
     for (p, name), v in by.items():
         if p == pid and any(x in name for x in ("k_stream", "k_scatter", "k_hist")):
             res[name.strip()] = {"launches": len(v), "mean_ms": round(sum(v) / len(v), 4), "min_ms": round(min(v), 4), "max_ms": round(max(v), 4)}
+per_kernel = defaultdict(dict)
 for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     c = rows(sub, "*counter_collection.csv")
     vals = defaultdict(list)
     for r in c:
-        if r.get("Counter_Name") == counter and "k_stream" in r.get("Kernel_Name", ""):
-            vals[r.get("Process_Id") or r["_file"]].append(float(r["Counter_Value"]))
-    if vals:
-        v = max(vals.values(), key=lambda x: max(x))
-        big = [x for x in v if x > 0.5 * max(v)]
-        res[counter] = {"launches": len(big), "mean_counter_value": sum(big) / len(big), "unit_note": "rocprofv3 derived counter, KB (1 KB = 1024 B) on this build"}
-if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
-    f, w = res["FETCH_SIZE"]["mean_counter_value"], res["WRITE_SIZE"]["mean_counter_value"]
+        if r.get("Counter_Name") == counter and any(x in r.get("Kernel_Name", "") for x in ("k_stream", "k_scatter", "k_hist")):
+            vals[r["Kernel_Name"].split("(")[0].strip()].append(float(r["Counter_Value"]))
+    for name, v in vals.items():
+        big = [x for x in v if x > 0.5 * max(v)]                  # the replay's launches (a small oracle-checked launch may ride along)
+        per_kernel[name][counter] = {"launches": len(big), "mean_counter_value": sum(big) / len(big)}
+res["pmc_per_kernel"] = {k: v for k, v in per_kernel.items()}
+res["pmc_unit_note"] = "rocprofv3 derived counters, KB (1 KB = 1024 B) on this build; separate passes per counter"
+# the EMIT variant of k_stream is the one that writes keys: the k_stream instantiation with the largest WRITE_SIZE
+emit = None
+for name, v in per_kernel.items():
+    if "k_stream" in name and "WRITE_SIZE" in v and "FETCH_SIZE" in v and (emit is None or v["WRITE_SIZE"]["mean_counter_value"] > per_kernel[emit]["WRITE_SIZE"]["mean_counter_value"]):
+        emit = name
+if emit:
+    f, w = per_kernel[emit]["FETCH_SIZE"]["mean_counter_value"], per_kernel[emit]["WRITE_SIZE"]["mean_counter_value"]
+    res["k_stream_emit_kernel"] = emit
+    res["FETCH_SIZE"] = per_kernel[emit]["FETCH_SIZE"]
+    res["WRITE_SIZE"] = per_kernel[emit]["WRITE_SIZE"]
     res["k_stream_bytes_per_launch"] = int((2 * f + w) * 1024)
     res["how"] = "2 x FETCH_SIZE (gfx950 reports half the bytes of wide streaming reads) + WRITE_SIZE, counters in KB"
 print(json.dumps(res, indent=1))

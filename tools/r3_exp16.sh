@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 3, GPU call 16: the BAM mapped, the device copying straight out of the page cache — against the copying reader
+cd "${GRAFT_REPO_ROOT:-.}"
+O=$PWD/gpurun_out/r3u
+mkdir -p $O
+export OMP_NUM_THREADS=16
+python -c "import __graft_entry__ as g; g.build()" > $O/build.txt 2>&1
+timeout -k 10 600 python -m pytest tests/test_gpu_bamwin.py tests/test_cli_golden.py tests/test_gpu_dedup.py -x -q > $O/pytest.txt 2>&1
+echo "pytest rc $?"; tail -4 $O/pytest.txt
+ITX_AB_MKBAM="content=hiseq cigar=mixed" timeout -k 10 1000 python tools/ab_cli.py 500000000 100 3 \
+  nommap:ITX_NO_MMAP=1 \
+  l5:ITX_LANES=5,ITX_PUSHES=10 \
+  > $O/cli_hiseq_500M.json 2> $O/cli_hiseq_500M.err
+echo "rc $?"; tail -3 $O/cli_hiseq_500M.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r3u/cli_hiseq_500M.json"))
+print(d["same_outputs_as_base"])
+for k in d["walls_s"]:
+    print(k, d["walls_s"][k], d["scan_s"][k], [l for l in d["notes"][k] if "device decoder" in l or "record loop" in l or "BAM decode" in l or "HIP runtime" in l or "table build" in l or "load " in l])
+PY
+WD=/tmp/itx_bench_r500000000_s100_t5500000_c0_hiseq_mixed
+timeout -k 10 300 bash tools/trace_cli.sh $WD $O/trace > $O/trace.log 2>&1
+python tools/trace_summary.py $O/trace > $O/trace_summary.txt 2>&1
+grep "itx timing" $O/trace/stderr.txt >> $O/trace_summary.txt
+cat $O/trace_summary.txt
+find $O -name "*.csv" -size +2M -delete

@@ -99,3 +99,18 @@ for r in m:
     cp[key][2] += int(r.get("Size", 0) or 0) if "Size" in r else 0
 for kx, (c, t, sz) in cp.items():
     print(f"copy {kx:22s} {c:6d} copies {t / 1e6:10.2f} ms total {sz / 1e9:8.2f} GB")
+# the big host-to-device copies (the compressed chunks): how long the link was busy with them and at what rate each ran
+big = []
+for r in m:
+    a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    sz = int(r.get("Size", 0) or 0) if "Size" in r else 0
+    if "HOST_TO_DEVICE" in r.get("Direction", "") and (sz >= (32 << 20) or (not sz and b - a > 2_000_000)):
+        big.append((a, b, sz))
+if big:
+    u = union([(a, b) for a, b, _ in big])
+    tot = sum(s for _, _, s in big)
+    rates = sorted((s / (b - a)) for a, b, s in big if s)
+    print(f"big H2D copies: {len(big)}, {tot / 1e9:.2f} GB, link busy with them {length(u) / 1e6:.1f} ms of a span of {(u[-1][1] - u[0][0]) / 1e6:.1f} ms"
+          + (f", per-copy rate median {rates[len(rates) // 2]:.1f} GB/s (min {rates[0]:.1f}, max {rates[-1]:.1f})" if rates else ""))
+    if tk:
+        print(f"pass 1 running {length(tk) / 1e6:.1f} ms; copies and pass 1 together {inter(u, tk) / 1e6:.1f} ms")

@@ -39,7 +39,10 @@ def main():
             for k, v in kv.items():
                 env[k] = os.path.join(ROOT, v) if k == "LD_LIBRARY_PATH" else v
             out = os.path.join(wd, "ab_" + name)
-            wall, rc, err, seen = bench.run_timed(bench.OURS, bench.base_args(wd) + [os.path.join(wd, "reads.bam")], out, env, (bench.SCAN_BEGIN, bench.SCAN_END))
+            args = bench.base_args(wd)
+            extra = os.environ.get("ITX_AB_OPTS", "").split()              # e.g. ITX_AB_OPTS="-R": options behind `stat -w`
+            args = args[:2] + extra + args[2:]
+            wall, rc, err, seen = bench.run_timed(bench.OURS, args + [os.path.join(wd, "reads.bam")], out, env, (bench.SCAN_BEGIN, bench.SCAN_END))
             assert rc == 0, err[-800:]
             walls[name].append(round(wall, 3))
             scans[name].append(round(seen.get(bench.SCAN_END, 0) - seen.get(bench.SCAN_BEGIN, 0), 3))

@@ -363,10 +363,6 @@ void itx_timing_report(void);
 /* Page-locked host memory for the buffers that cross PCIe on every call (NULL when it cannot be had). */
 void *itx_pinned_alloc(size_t bytes);
 void itx_pinned_free(void *p);
-/* page-lock / release memory the caller already has (a read-only mapping of a file: the device then copies straight out of the page
- * cache; host/bamio.c with ITX_MMAP=1) */
-int itx_host_register(void *p, size_t bytes);
-int itx_host_unregister(void *p);
 
 #ifdef __cplusplus
 }

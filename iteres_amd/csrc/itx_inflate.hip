@@ -539,25 +539,6 @@ extern "C" void itx_pinned_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
-/* page-locks memory the caller already has (a read-only mapping of a file: the device then copies straight out of the page cache) */
-extern "C" int itx_host_register(void *p, size_t bytes)
-{
-    if (!p || !bytes) return ITX_E_ARG;
-    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
-    if (e != hipSuccess) {
-        itx_set_error("hipHostRegister(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        (void)hipGetLastError();
-        return ITX_E_NOMEM;
-    }
-    return ITX_OK;
-}
-
-extern "C" int itx_host_unregister(void *p)
-{
-    if (!p) return ITX_E_ARG;
-    return hipHostUnregister(p) == hipSuccess ? ITX_OK : ITX_E_STATE;
-}
-
 // ITX_TIMING: where the decoder's device-side time goes (printed when the process ends)
 static double g_alloc_s, g_tok_ms, g_res_ms;
 static unsigned long g_allocs, g_pushes;

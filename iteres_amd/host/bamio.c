@@ -13,8 +13,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
-#include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -62,12 +60,6 @@ struct aln_reader {
     int io_fd;                /* >= 0: a regular file, read with pread at io_off (of io_size bytes)              */
     size_t io_off, io_size;
     size_t raw_step;          /* bytes per read step (aln_raw_step) */
-    uint8_t *map;             /* ITX_MMAP=1, the device decoder on a regular file: the whole file mapped read-only (cbuf points into it) */
-    size_t map_len;
-#define MAP_RANGES 32
-    size_t mr_a[MAP_RANGES], mr_b[MAP_RANGES];   /* page-locked ranges of the mapping (file offsets), oldest at mr_head % MAP_RANGES */
-    long mr_head, mr_tail;
-    size_t reg_end, unmapped_upto;               /* the mapping is page-locked up to reg_end; released (and unmapped) below unmapped_upto */
     void (*win_hook)(void *, size_t);   /* aln_set_window_hook */
     void *win_hook_ctx;
     int io_on, io_stop, io_done; /* io_done: the file is read out and its last chunk taken */
@@ -457,61 +449,9 @@ size_t aln_raw_step(size_t left)
  * a quarter of the record loop of a BAM the device takes at the rate the page cache delivers it); else one */
 static long io_ahead(const aln_reader *r) { return r->n_raw == N_RAW_DEVICE_FILE ? r->n_raw - 3 : 0; }
 
-static long pushes_in_flight(void);
-/* ITX_MMAP=1: this thread page-locks the mapping a few steps ahead of the producer (12 ms per GB: the pages are in the page
- * cache already) and lets go of what lies two steps behind it — unlocked and unmapped piece by piece, so that no 56 GB of
- * page tables are left to tear down at the end */
-static void *io_main_mapped(aln_reader *r)
-{
-    const size_t gran = (size_t)2 << 20;
-    pthread_mutex_lock(&r->io_mu);
-    for (;;) {
-        int act = 0;
-        while (!r->io_stop) {
-            if (r->mr_head < r->mr_tail && r->io_off >= r->mr_b[r->mr_head % MAP_RANGES] + 2 * r->raw_step) {
-                act = 2;
-                break;
-            }
-            if (r->reg_end < r->io_size && r->reg_end < r->io_off + 3 * r->raw_step && r->mr_tail - r->mr_head < MAP_RANGES) {
-                act = 1;
-                break;
-            }
-            pthread_cond_wait(&r->io_cv, &r->io_mu);
-        }
-        if (r->io_stop) break;
-        if (act == 1) {
-            const size_t a = r->reg_end;
-            size_t b = (a + r->raw_step + gran - 1) & ~(gran - 1);
-            if (b > r->io_size) b = r->io_size;
-            pthread_mutex_unlock(&r->io_mu);
-            if (dev.host_register(r->map + a, b - a) != 0) die("cannot page-lock %zu bytes of the mapped alignment file: %s", b - a, dev.last_error ? dev.last_error() : "?");
-            pthread_mutex_lock(&r->io_mu);
-            r->mr_a[r->mr_tail % MAP_RANGES] = a;
-            r->mr_b[r->mr_tail % MAP_RANGES] = b;
-            r->mr_tail++;
-            r->reg_end = b;
-        } else {
-            const size_t a = r->mr_a[r->mr_head % MAP_RANGES], b = r->mr_b[r->mr_head % MAP_RANGES];
-            pthread_mutex_unlock(&r->io_mu);
-            /* the producer is two steps past it: its pushes were begun long ago; the copy stream is one queue, so once the
-             * newest copies have left their buffers so have these */
-            for (int sl = 0; sl < pushes_in_flight(); sl++) DEV_CHK(dev.push_copied(dev.ctx, sl), "push_copied");
-            (void)dev.host_unregister(r->map + a);
-            if ((b & 4095u) == 0) munmap(r->map + a, b - a);       /* (the file's last piece goes with the rest at close) */
-            pthread_mutex_lock(&r->io_mu);
-            r->mr_head++;
-            if ((b & 4095u) == 0) r->unmapped_upto = b;
-        }
-        pthread_cond_broadcast(&r->io_cv);
-    }
-    pthread_mutex_unlock(&r->io_mu);
-    return NULL;
-}
-
 static void *io_main(void *arg)
 {
     aln_reader *r = arg;
-    if (r->map) return io_main_mapped(r);
     pthread_mutex_lock(&r->io_mu);
     for (;;) {
         /* chunk io_fill goes into buffer io_fill % n_raw, last used by chunk io_fill - n_raw: raw_next has long moved on from it */
@@ -598,26 +538,11 @@ static size_t raw_next(aln_reader *r)
             if (r->dev && r->io_fd >= 0 && dev.push_copied) r->n_raw = N_RAW_DEVICE_FILE;
         }
         r->raw_step = r->io_fd >= 0 ? aln_raw_step(r->io_size > r->io_off ? r->io_size - r->io_off : 0) : RAW_STEP;
-        /* ITX_MMAP=1 (an experiment that lost, kept for the record): the file is MAPPED and the device copies a chunk's bytes
-         * straight out of the page cache, which would save the 11 core-seconds the eight pread threads spend per 56 GB — of the
-         * 16 cores a GPU's share of the box has. A plain hipMemcpy from a read-only mapping does run at 55 GB/s
-         * (profiles/r03_mmap_probe.txt), and the table build beside it takes 0.19 - 0.34 s instead of 0.45 - 0.85; but the
-         * asynchronous copies of the pipeline go through the runtime's staging path in pieces (2027 copies for 139 pushes) and
-         * hold the producer thread, and tearing down the page tables of 56 GB of touched mapping costs 0.58 s at close:
-         * 4.0 - 4.1 s per run against 3.2 - 3.8 s (profiles/r03_cli_500M_hiseq_mmap.json). */
-        if (r->n_raw == N_RAW_DEVICE_FILE && getenv("ITX_MMAP") && r->io_size > 0) {
-            void *m = mmap(NULL, r->io_size, PROT_READ, MAP_SHARED, r->io_fd, 0);
-            if (m != MAP_FAILED && dev.host_register && dev.host_unregister) {
-                r->map = m;
-                r->map_len = r->io_size;
-                r->cbuf = r->map + r->io_off;
-                r->clen = 0;
-                r->reg_end = r->unmapped_upto = r->io_off & ~(size_t)4095;
-                r->mr_head = r->mr_tail = 0;
-            } else if (m != MAP_FAILED) {
-                munmap(m, r->io_size);
-            }
-        }
+        /* (Mapping the file and letting the device copy straight out of the page cache was tried twice and lost: through the
+         * runtime's own path for unlocked memory the pipeline's copies go in staged pieces and hold the producer, 4.0 - 4.1 s per
+         * run against 3.0 - 3.4 s; page-locking the mapping ahead with hipHostRegister costs 62 ms per GB — 3.5 s for the 56 GB
+         * file, more when several threads do it — against the 11 core-seconds of pread it was meant to save:
+         * profiles/r03_mmap_probe.txt, r03_cli_500M_hiseq_mmap*.json.) */
         pthread_mutex_init(&r->io_mu, NULL);
         pthread_cond_init(&r->io_cv, NULL);
         r->io_fill = r->io_take = 0;
@@ -625,21 +550,6 @@ static size_t raw_next(aln_reader *r)
         r->io_stop = 0;
         if (pthread_create(&r->io_thread, NULL, io_main, r) != 0) die("cannot start the file read-ahead thread");
         r->io_on = 1;
-    }
-    if (r->map) {
-        /* the next step's bytes are simply there, behind what the indexer left over (no carry: the file is one piece), once
-         * the registrar has page-locked them */
-        size_t got = r->io_size > r->io_off ? r->io_size - r->io_off : 0;
-        if (got > r->raw_step) got = r->raw_step;
-        pthread_mutex_lock(&r->io_mu);
-        while (r->reg_end < r->io_off + got) pthread_cond_wait(&r->io_cv, &r->io_mu);
-        r->io_off += got;
-        pthread_cond_broadcast(&r->io_cv);
-        pthread_mutex_unlock(&r->io_mu);
-        r->clen += got;
-        r->io_abs_end += got;
-        if (got < r->raw_step) r->io_done = 1;
-        return got;
     }
     pthread_mutex_lock(&r->io_mu);
     while (r->io_fill <= r->io_take) pthread_cond_wait(&r->io_cv, &r->io_mu);
@@ -840,7 +750,7 @@ static void dev_begin(aln_reader *r)
     j->nb = nb_use;
     j->cbase = r->cbuf;
     j->cabs = r->io_fd >= 0 ? r->io_abs_end - r->clen : SIZE_MAX;
-    if (r->n_raw == N_RAW_DEVICE_FILE && r->io_on && !r->map) {
+    if (r->n_raw == N_RAW_DEVICE_FILE && r->io_on) {
         pthread_mutex_lock(&r->io_mu);
         r->raw_lanes[r->raw_cur] |= 1u << (k % pushes_in_flight());
         pthread_mutex_unlock(&r->io_mu);
@@ -1433,10 +1343,6 @@ void aln_close(aln_reader *r)
         pthread_cond_broadcast(&r->io_cv);
         pthread_mutex_unlock(&r->io_mu);
         pthread_join(r->io_thread, NULL);
-    }
-    if (r->map) {                                                              /* (every push has ended: nothing copies out of it any more) */
-        for (; r->mr_head < r->mr_tail; r->mr_head++) (void)dev.host_unregister(r->map + r->mr_a[r->mr_head % MAP_RANGES]);
-        if (r->unmapped_upto < r->map_len) munmap(r->map + r->unmapped_upto, r->map_len - r->unmapped_upto);
     }
     if (r->f) fclose(r->f);
     for (int k = 0; k < N_RAW_DEVICE; k++) buf_free(r->craw[k]);

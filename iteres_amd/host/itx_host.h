@@ -99,8 +99,6 @@ typedef struct aln_device_ops {
     size_t max_blocks, max_bytes;
     int (*xa_veto)(itx_inflater *, itx_xaveto *, size_t, size_t, uint64_t *, uint64_t *);      /* itx_bamwin_xa_veto */
     int (*push_copied)(itx_inflater *, int);       /* itx_bamwin_push_copied: lane s's compressed bytes have left the caller's buffer */
-    int (*host_register)(void *, size_t);          /* itx_host_register / itx_host_unregister (ITX_MMAP=1: chunks of the mapped file) */
-    int (*host_unregister)(void *);
 } aln_device_ops;
 void aln_use_device(const aln_device_ops *ops);
 size_t aln_raw_step(size_t left);           /* bytes per read step of a regular file with `left` bytes to go (after aln_use_device) */

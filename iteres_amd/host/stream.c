@@ -87,7 +87,7 @@ static void use_device_reader(void)
 {
     const aln_device_ops ops = {g_inflater,       itx_bamwin_push_begin, itx_bamwin_push_end, itx_bamwin_patch, itx_bamwin_truncate, itx_bamwin_carry, itx_bamwin_avail, itx_bamwin_peek,
                                 itx_bamwin_skip, itx_bamwin_parse, itx_bamwin_fetch, itx_bamwin_bytes,    itx_bamwin_tids,  itx_bamwin_device_batch,
-                                pool_alloc,      pool_release,     itx_last_error,   g_dev_windows,       g_dev_max_blocks, g_dev_max_bytes, itx_bamwin_xa_veto, itx_bamwin_push_copied, itx_host_register, itx_host_unregister};
+                                pool_alloc,      pool_release,     itx_last_error,   g_dev_windows,       g_dev_max_blocks, g_dev_max_bytes, itx_bamwin_xa_veto, itx_bamwin_push_copied};
     aln_use_device(&ops);
 }
 

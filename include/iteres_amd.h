@@ -331,6 +331,18 @@ int32_t *itx_xaveto_hits(itx_xaveto *x);
 void *itx_xaveto_stream(itx_xaveto *x);
 int itx_bamwin_xa_veto(itx_inflater *h, itx_xaveto *x, size_t first, size_t n, uint64_t *n_vetoed, uint64_t *n_hard);
 
+/* ---- a backlog of parsed records in HBM -----------------------------------------------------------------------------
+ * What a caller keeps of windows it parses BEFORE its table exists (the engine cannot take them yet): the per-record arrays
+ * only — 14 B per record, 22 with mates, a ninth of the inflated bytes — so that the windows can be pushed into again and the
+ * decode goes on while the rmsk file is parsed and the table built (host/stream.c: the helper thread). append copies n records
+ * (device arrays) and says where they lie (a multiple of 16); batch gives that place back as an itx_batch. */
+typedef struct itx_backlog itx_backlog;
+int itx_backlog_create(int device, size_t max_records, itx_backlog **out);
+void itx_backlog_destroy(itx_backlog *b);
+size_t itx_backlog_room(const itx_backlog *b);
+int itx_backlog_append(itx_backlog *b, const itx_batch *src, size_t n, size_t *at);
+int itx_backlog_batch(const itx_backlog *b, size_t at, int with_mates, itx_batch *out);
+
 /* ---- -R (remove redundant reads) on the device --------------------------------------------------------------------
  * Replaces generic.c:907-919 (filter copy 544-556): the `dup` hash of "chr:start:end:strand" keys and the `continue` behind
  * it. As a rule per record, records numbered in file order: one with MAPQ >= -Q is dropped iff an earlier one with MAPQ >= -Q

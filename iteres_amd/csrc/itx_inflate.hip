@@ -539,6 +539,98 @@ extern "C" void itx_pinned_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// A backlog of parsed records in HBM (SoA, 14 B per record, 22 with mates): the caller parses windows while its table is
+// still being built, keeps only what the engine will read — a ninth of the inflated bytes — and lets the windows go
+// (host/stream.c). Offsets are multiples of 16 records (itx_engine_submit_device* wants batches to start there).
+struct itx_backlog {
+    int device;
+    size_t cap, used;
+    int32_t *tid, *pos, *end, *mpos, *isize;
+    uint8_t *mapq, *f5;
+    hipStream_t st;
+};
+
+extern "C" int itx_backlog_create(int device, size_t max_records, itx_backlog **out)
+{
+    if (!out || max_records == 0 || max_records >= ((size_t)1 << 31)) return ITX_E_ARG;
+    *out = nullptr;
+    INF_HIP(hipSetDevice(device));
+    itx_backlog *b = (itx_backlog *)calloc(1, sizeof *b);
+    if (!b) return ITX_E_NOMEM;
+    b->device = device;
+    b->cap = (max_records + 15) & ~(size_t)15;
+    const size_t n = b->cap + 64;
+    if (hipMalloc((void **)&b->tid, n * 4) != hipSuccess || hipMalloc((void **)&b->pos, n * 4) != hipSuccess || hipMalloc((void **)&b->end, n * 4) != hipSuccess ||
+        hipMalloc((void **)&b->mapq, n) != hipSuccess || hipMalloc((void **)&b->f5, n) != hipSuccess || hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) {
+        itx_set_error("itx_backlog_create: no device memory for %zu records", max_records);
+        (void)hipGetLastError();
+        (void)hipFree(b->tid); (void)hipFree(b->pos); (void)hipFree(b->end); (void)hipFree(b->mapq); (void)hipFree(b->f5);
+        free(b);
+        return ITX_E_NOMEM;
+    }
+    *out = b;
+    return ITX_OK;
+}
+
+extern "C" void itx_backlog_destroy(itx_backlog *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->st) {
+        (void)hipStreamSynchronize(b->st);
+        (void)hipStreamDestroy(b->st);
+    }
+    (void)hipFree(b->tid); (void)hipFree(b->pos); (void)hipFree(b->end); (void)hipFree(b->mapq); (void)hipFree(b->f5);
+    (void)hipFree(b->mpos); (void)hipFree(b->isize);
+    free(b);
+}
+
+/* room left, in records */
+extern "C" size_t itx_backlog_room(const itx_backlog *b) { return b ? b->cap - b->used : 0; }
+
+/* appends n records (DEVICE arrays; mpos / isize NULL: no mates) — copied, the source may be reused when the call returns;
+ * *at = where they lie (a multiple of 16). ITX_E_LIMIT: no room (nothing copied). */
+extern "C" int itx_backlog_append(itx_backlog *b, const itx_batch *src, size_t n, size_t *at)
+{
+    if (!b || !src || !at || !src->tid || !src->pos || !src->tmpend || !src->mapq || !src->flag5) return ITX_E_ARG;
+    if (n > b->cap - b->used) return ITX_E_LIMIT;
+    INF_HIP(hipSetDevice(b->device));
+    const size_t o = b->used;
+    if (src->mpos && src->isize && !b->mpos) {
+        const size_t m = b->cap + 64;
+        INF_HIP(hipMalloc((void **)&b->mpos, m * 4));
+        INF_HIP(hipMalloc((void **)&b->isize, m * 4));
+    }
+    INF_HIP(hipMemcpyAsync(b->tid + o, src->tid, n * 4, hipMemcpyDeviceToDevice, b->st));
+    INF_HIP(hipMemcpyAsync(b->pos + o, src->pos, n * 4, hipMemcpyDeviceToDevice, b->st));
+    INF_HIP(hipMemcpyAsync(b->end + o, src->tmpend, n * 4, hipMemcpyDeviceToDevice, b->st));
+    INF_HIP(hipMemcpyAsync(b->mapq + o, src->mapq, n, hipMemcpyDeviceToDevice, b->st));
+    INF_HIP(hipMemcpyAsync(b->f5 + o, src->flag5, n, hipMemcpyDeviceToDevice, b->st));
+    if (src->mpos && src->isize) {
+        INF_HIP(hipMemcpyAsync(b->mpos + o, src->mpos, n * 4, hipMemcpyDeviceToDevice, b->st));
+        INF_HIP(hipMemcpyAsync(b->isize + o, src->isize, n * 4, hipMemcpyDeviceToDevice, b->st));
+    }
+    INF_HIP(hipStreamSynchronize(b->st));
+    *at = o;
+    b->used = (o + n + 15) & ~(size_t)15;
+    return ITX_OK;
+}
+
+/* the records at `at` as a batch for itx_engine_submit_device* (with_mates: the batch was appended with mates) */
+extern "C" int itx_backlog_batch(const itx_backlog *b, size_t at, int with_mates, itx_batch *out)
+{
+    if (!b || !out || at > b->used || (at & 15u) || (with_mates && !b->mpos)) return ITX_E_ARG;
+    out->tid = b->tid + at;
+    out->pos = b->pos + at;
+    out->tmpend = b->end + at;
+    out->mapq = b->mapq + at;
+    out->flag5 = b->f5 + at;
+    out->mpos = with_mates ? b->mpos + at : nullptr;
+    out->isize = with_mates ? b->isize + at : nullptr;
+    return ITX_OK;
+}
+
 // ITX_TIMING: where the decoder's device-side time goes (printed when the process ends)
 static double g_alloc_s, g_tok_ms, g_res_ms;
 static unsigned long g_allocs, g_pushes;

@@ -28,7 +28,7 @@ EXPORTS = [
     "itx_bamwin_parse", "itx_bamwin_fetch", "itx_bamwin_bytes", "itx_bamwin_tids", "itx_bamwin_device_batch",
     "itx_engine_submit_device_own", "itx_engine_wait_own",
     "itx_engine_partial_buffers", "itx_inflater_reserve", "itx_inflater_last_resolve_all_ms", "itx_timing_report", "itx_xaveto_create", "itx_xaveto_destroy", "itx_xaveto_set_tidmap", "itx_xaveto_hits", "itx_xaveto_stream", "itx_bamwin_xa_veto", "itx_comm_create", "itx_comm_destroy", "itx_comm_reduce_sum",
-    "itx_dedup_create", "itx_dedup_destroy", "itx_dedup_set_tidmap", "itx_dedup_run", "itx_dedup_counts", "itx_bamwin_dedup",
+    "itx_backlog_create", "itx_backlog_destroy", "itx_backlog_room", "itx_backlog_append", "itx_backlog_batch", "itx_dedup_create", "itx_dedup_destroy", "itx_dedup_set_tidmap", "itx_dedup_run", "itx_dedup_counts", "itx_bamwin_dedup",
 ]
 
 

@@ -47,7 +47,7 @@ struct aln_reader {
     size_t clen;              /* a window into one of the two raw buffers below                                 */
     /* raw read-ahead (raw_next): a reader thread freads the next compressed chunk while this one is being inflated */
 #define N_RAW_DEVICE (ITX_BAMWIN_LANES + 2)
-#define N_RAW_DEVICE_FILE 5
+#define N_RAW_DEVICE_FILE ALN_DEVICE_RAW_BUFFERS
     uint8_t *craw[N_RAW_DEVICE]; /* two for the host decoder. The device's, from a regular file: one being indexed, one whose pushes are
                                   * copying, the others read ahead (a buffer is free again once the pushes cut from it have COPIED their bytes: a
                                   * block the device declines is read from the file once more); from a pipe: one per push in flight + 2, held

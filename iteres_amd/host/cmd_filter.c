@@ -103,9 +103,11 @@ int main_filter(int argc, char **argv)
     /* what is order-dependent stays with one rank: -R, the read-name lists (-r), SAM text */
     const int splittable = !o.is_sam && !o.dedup && !optreadlist;
     multi_begin(splittable, o.aln_arg, 0);
+    stream_prefetch_allow(&o, 1, !o.is_sam && !o.dedup && !optreadlist);
     gpu_warmup_start(!o.is_sam, o.aln_arg, 0, splittable);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
+    stream_sizes_ready(&chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);
     fprintf(stderr, "* Start to parse the rmsk file\n");
     rmsk_t rm;

@@ -132,9 +132,11 @@ int main_stat(int argc, char **argv)
     /* what is order-dependent stays with one rank: -R, the bed files, SAM text; everything else shards by record */
     const int splittable = !o.is_sam && !o.dedup && !optBed && !optBedUniq;
     multi_begin(splittable, o.aln_arg, 1);
+    stream_prefetch_allow(&o, 0, !o.is_sam && !o.dedup && !optBed && !optBedUniq);
     gpu_warmup_start(!o.is_sam, o.aln_arg, 1, splittable);
     sizes_t chr_sizes, rep_sizes;
     sizes_load(o.chr_size_file, &chr_sizes);
+    stream_sizes_ready(&chr_sizes);
     sizes_load(o.rep_size_file, &rep_sizes);
     fprintf(stderr, "* Parsing the rmsk file\n");
     rmsk_t rm;

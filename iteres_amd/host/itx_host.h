@@ -108,6 +108,7 @@ size_t aln_raw_step(size_t left);           /* bytes per read step of a regular 
  * take ~33 KB compressed, so 384 MB = 12 k blocks per push, four pushes in flight = 48 k blocks (round 2: 128 MB, written for
  * blocks of 15 KB). Measured, 200 M reads of 40-value-quality content: record loop 1.35 s -> 0.64 s. */
 #define ALN_DEVICE_CHUNK (384u << 20)
+#define ALN_DEVICE_RAW_BUFFERS 5             /* page-locked chunk buffers the reader of a regular file rotates through (bamio.c) */
 /* Device decoder only. aln_device_window: 1 when the next records can be taken as DEVICE arrays — the reader stands at
  * the start of a decoded window (decoding the next one if need be); *flags: bit 0 some record of the window is paired,
  * bit 1 some record carries an XA tag; *tid_seen[n_targets]: references with a mapped record in the window. 0: host
@@ -186,6 +187,10 @@ char *filename_without_ext(const char *path);
 /* Runs the record loop (generic.c:700-1062 / 343-697) over one or more files through the engine.
  * progress_every: 100000 (stat, generic.c:760) or 10000 (filter, generic.c:397). want_qnames: per-locus read
  * names (filter -r): *locus_names[row] receives a comma-joined list in BAM order. */
+/* records parsed ahead of the table by the helper thread (stream.c): allowed when nothing per record is the host's business;
+ * the size file's table has to be announced once it is loaded */
+void stream_prefetch_allow(const run_opts *o, int filter_mode, int allowed);
+void stream_sizes_ready(const sizes_t *chr_sizes);
 void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file, int splittable);  /* starts the HIP runtime on a helper thread (and, for BAM input, the device inflater with its
                                         * page-locked buffers); run_stream joins it */
 void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, int filter_mode, int multi_file,

@@ -41,12 +41,18 @@ static itx_inflater *g_inflater;
 #define POOL_N (ITX_BAMWIN_LANES + 2)
 static struct { void *p; size_t cap; int used; } pool[POOL_N];
 static pthread_mutex_t pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t pool_cv = PTHREAD_COND_INITIALIZER;
+static int pool_pinning;                       /* buffers the pinning thread (pin_main) has yet to deliver */
 static void *pool_alloc(size_t n)
 {
     pthread_mutex_lock(&pool_mu);
     int best = -1;
-    for (int i = 0; i < POOL_N; i++)
-        if (pool[i].p && !pool[i].used && pool[i].cap >= n && (best < 0 || pool[i].cap < pool[best].cap)) best = i;
+    for (;;) {
+        for (int i = 0; i < POOL_N; i++)
+            if (pool[i].p && !pool[i].used && pool[i].cap >= n && (best < 0 || pool[i].cap < pool[best].cap)) best = i;
+        if (best >= 0 || pool_pinning <= 0) break;
+        pthread_cond_wait(&pool_cv, &pool_mu);                       /* one is being locked right now: it will be here sooner than one of our own */
+    }
     if (best >= 0) pool[best].used = 1;
     pthread_mutex_unlock(&pool_mu);
     if (best >= 0) return pool[best].p;
@@ -159,14 +165,112 @@ static void *early_comm_main(void *arg)
     return NULL;
 }
 
+/* generic.c:781-801 for one reference name of a BAM header: its chromosome in the size file, -1 when it is not there (or its
+ * size reads as "not found": generic.c:796-797), -2 when -C drops it */
+static const char *rename_chr(const char *name, int add_chr, char *buf, size_t bufsz);
+static int32_t chrom_of_target(const char *target, const run_opts *o, const sizes_t *chr_sizes)
+{
+    char buf[4096];
+    const char *nm = rename_chr(target, o->add_chr, buf, sizeof buf);
+    if (!nm) return -2;
+    const int64_t id = names_find(&chr_sizes->names, nm);
+    return (id >= 0 && (int)chr_sizes->value[id] != 2) ? (int32_t)id : -1;
+}
+
+/* ---- records parsed AHEAD of the table -------------------------------------------------------------------------------
+ * The engine cannot take records before the table is on the device, and the ring of windows holds 0.1 s of decode: the decoder
+ * used to sit idle for the rest of the rmsk parse and the table build. Now the helper thread goes on after it has opened the
+ * first file: it parses the windows as they come, keeps their records in a backlog in HBM (include/iteres_amd.h itx_backlog_*:
+ * 14 bytes per record instead of the 220 of the inflated stream) and lets the windows go back to the decoder. run_stream
+ * submits the backlog first, in order. Only when nothing per record is the host's business (no -R, no bed files, no name
+ * lists), one rank, and only whole windows without XA tags (the veto reads the window's bytes) and without mapped records on
+ * chromosomes the size file lacks (their warnings are per record): the first window that does not qualify ends it and is
+ * left, untouched, to the loop. ITX_NO_PREFETCH=1 turns it off. */
+static const run_opts *pre_opts;
+static int pre_filter_mode, pre_allowed;
+static const sizes_t *pre_sizes;              /* set when the size file is loaded (stream_sizes_ready) */
+static int pre_stop;                           /* run_stream: table and engine are there */
+static itx_backlog *pre_bl;
+static struct pre_ent { size_t at, n; int paired; } *pre_v;
+static size_t pre_n, pre_cap;
+static double pre_seconds;
+void stream_prefetch_allow(const run_opts *o, int filter_mode, int allowed)
+{
+    pre_opts = o;
+    pre_filter_mode = filter_mode;
+    pre_allowed = allowed;
+}
+void stream_sizes_ready(const sizes_t *chr_sizes) { __atomic_store_n(&pre_sizes, chr_sizes, __ATOMIC_RELEASE); }
+
+static void prefetch_records(aln_reader *rd)
+{
+    const double t0 = now_s();
+    const sizes_t *cs = NULL;
+    while (!(cs = __atomic_load_n(&pre_sizes, __ATOMIC_ACQUIRE))) {            /* (loaded milliseconds after this thread started) */
+        if (__atomic_load_n(&pre_stop, __ATOMIC_ACQUIRE) || now_s() - t0 > 10) return;
+        usleep(200);
+    }
+    const run_opts *o = pre_opts;
+    const int nt = aln_n_targets(rd);
+    if (nt <= 0) return;
+    int32_t *t2c = xmalloc(sizeof(int32_t) * (size_t)nt);
+    for (int t = 0; t < nt; t++) t2c[t] = chrom_of_target(aln_target_name(rd, t), o, cs);
+    size_t cap = warm_input_bytes / 60 + ((size_t)1 << 20);                     /* no BAM record takes less than that compressed */
+    if (cap > ((size_t)160 << 20)) cap = (size_t)160 << 20;
+    if (itx_backlog_create(multi_device(), cap, &pre_bl) != ITX_OK) {
+        pre_bl = NULL;
+        free(t2c);
+        return;
+    }
+    const int veto_on = o->xa_veto && !pre_filter_mode;
+    while (!__atomic_load_n(&pre_stop, __ATOMIC_ACQUIRE)) {
+        int wfl = 0, ok = 1;
+        const uint8_t *seen = NULL;
+        if (!aln_device_window(rd, &wfl, &seen)) break;                         /* end of input */
+        if (veto_on && (wfl & 2)) break;
+        for (int t = 0; t < nt && ok; t++)
+            if (seen[t] && t2c[t] == -1) ok = 0;
+        if (!ok || aln_device_left(rd) > itx_backlog_room(pre_bl)) break;
+        itx_batch db;
+        const size_t n = aln_read_batch_device(rd, SIZE_MAX, &db);
+        if (n == 0) break;
+        size_t at = 0;
+        if (itx_backlog_append(pre_bl, &db, n, &at) != ITX_OK) die("records parsed ahead: %s", itx_last_error());
+        if (pre_n == pre_cap) {
+            pre_cap = pre_cap ? pre_cap * 2 : 64;
+            pre_v = xrealloc(pre_v, sizeof *pre_v * pre_cap);
+        }
+        pre_v[pre_n].at = at;
+        pre_v[pre_n].n = n;
+        pre_v[pre_n].paired = db.mpos != NULL;
+        pre_n++;
+    }
+    free(t2c);
+    pre_seconds = now_s() - t0;
+}
+
+/* Page-locks the reader's chunk buffers, one after the other, from the moment the HIP runtime is up (0.1 s each for 384 MB):
+ * the reader thread used to lock the third to fifth itself when it first needed them — 0.3 s during which the pipeline of
+ * pushes crawled (one window decoded in the first 0.34 s). */
 static size_t pin_want;
+static int pin_count;
 static void *pin_main(void *arg)
 {
     (void)arg;
-    for (int i = 0; i < 2 && i < POOL_N; i++) {
-        pool[i].p = itx_pinned_alloc(pin_want);
-        pool[i].cap = pool[i].p ? pin_want : 0;
+    for (int i = 0; i < pin_count && i < POOL_N; i++) {
+        void *p = itx_pinned_alloc(pin_want);
+        pthread_mutex_lock(&pool_mu);
+        pool[i].p = p;
+        pool[i].cap = p ? pin_want : 0;
+        pool[i].used = 0;
+        pool_pinning--;
+        pthread_cond_broadcast(&pool_cv);
+        pthread_mutex_unlock(&pool_mu);
     }
+    pthread_mutex_lock(&pool_mu);
+    pool_pinning = 0;
+    pthread_cond_broadcast(&pool_cv);
+    pthread_mutex_unlock(&pool_mu);
     return NULL;
 }
 
@@ -195,15 +299,24 @@ static void *warm_main(void *arg)
         const size_t mine_bytes = warm_input_bytes ? warm_input_bytes / (size_t)(multi_world() > 0 ? multi_world() : 1) : 0;
         step = mine_bytes && !ce ? aln_raw_step(mine_bytes + mine_bytes / 64) : chunk;
         pin_want = step + (1u << 17);
+        /* as many as a file of this size makes the reader use */
+        pin_count = warm_input_bytes ? (int)(mine_bytes / step + 1) : 2;
+        if (pin_count > ALN_DEVICE_RAW_BUFFERS) pin_count = ALN_DEVICE_RAW_BUFFERS;
+        if (getenv("ITX_PIN_EARLY") && atoi(getenv("ITX_PIN_EARLY")) >= 1 && atoi(getenv("ITX_PIN_EARLY")) < pin_count) pin_count = atoi(getenv("ITX_PIN_EARLY"));   /* (A/B) */
+        pool_pinning = pin_count;
         pin_on = pthread_create(&pin_th, NULL, pin_main, NULL) == 0;
+        if (!pin_on) pool_pinning = 0;
     }
     if (ndev > 0 && warm_bam && !getenv("ITX_HOST_INFLATE") && (inf_rc = itx_inflater_create(multi_device(), &g_inflater)) != ITX_OK)
         snprintf(warm_err, sizeof warm_err, "%s", itx_last_error());
     else if (ndev <= 0)
         snprintf(warm_err, sizeof warm_err, "no usable GPU (%s)", itx_last_error());
     t_created = now_s();
-    if (pin_on) pthread_join(pin_th, NULL);
-    else if (g_inflater) pin_main(NULL);
+    if (!pin_on && g_inflater) {
+        pin_count = 2;
+        pool_pinning = 2;
+        pin_main(NULL);
+    }
     t_pinned = now_s();
     if (!g_inflater) aln_use_device(NULL);                              /* it did not come up: the host decodes (run_stream says why when that will not do) */
     if (g_inflater) {
@@ -257,9 +370,16 @@ static void *warm_main(void *arg)
         }
         if (warm_reader) aln_readahead(warm_reader);
     }
+    const double t_opened = now_s();
     if (getenv("ITX_TIMING"))
         fprintf(stderr, "[itx timing] HIP runtime start-up %.3f s, device inflater + page-locked buffers %.3f s (streams %.3f, page-locked %.3f, device reserve %.3f), first file opened %.3f s (helper thread)\n", b - a,
-                c - b, t_created - b, t_pinned - t_created, c - t_pinned, now_s() - c);
+                c - b, t_created - b, t_pinned - t_created, c - t_pinned, t_opened - c);
+    {
+        const char *me = getenv("ITX_PREFETCH_MIN");                       /* bytes of input below which it is not worth a backlog (tests: 0) */
+        const size_t min_bytes = me ? (size_t)atoll(me) : (size_t)1 << 30;
+        if (warm_reader && pre_allowed && pre_opts && multi_world() <= 1 && warm_input_bytes >= min_bytes && !getenv("ITX_NO_PREFETCH")) prefetch_records(warm_reader);
+    }
+    if (pin_on) pthread_join(pin_th, NULL);                              /* (long done: it started when the runtime came up) */
     return NULL;
 }
 void gpu_warmup_start(int bam_input, const char *aln_arg, int multi_file, int splittable)
@@ -475,6 +595,8 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
     /* the helper thread (HIP start-up, device decoder, first file opened and decoding ahead) has had the rmsk parse and the
      * table build to finish */
     const double t_join = now_s();
+    if (getenv("ITX_PREFETCH_HOLD_MS")) usleep((useconds_t)atol(getenv("ITX_PREFETCH_HOLD_MS")) * 1000u);     /* tests: a table that takes its time */
+    __atomic_store_n(&pre_stop, 1, __ATOMIC_RELEASE);                  /* table and engine are there: the helper thread finishes the window it is at */
     gpu_warmup_join();
     if (timing) fprintf(stderr, "[itx timing] waited %.3f s for the helper thread\n", now_s() - t_join);
     if (g_inflater) use_device_reader();
@@ -506,9 +628,11 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
         if (share[fi].lo == share[fi].hi) continue;                      /* nothing of this file is this rank's */
         const double t_open0 = now_s();
         aln_reader *rd = NULL;
+        int drain_backlog = 0;
         if (fi == 0 && pass == 0 && warm_reader && warm_first && strcmp(files[0], warm_first) == 0 && warm_lo == share[0].lo && warm_hi == share[0].hi) {
             rd = warm_reader;                                            /* opened and decoding since the helper thread came up */
             warm_reader = NULL;
+            drain_backlog = pre_bl != NULL;
         } else {
             if (warm_reader && fi == 0 && pass == 0) {                   /* opened for another share than this plan's: not used */
                 aln_close(warm_reader);
@@ -532,9 +656,8 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
             if (!nm) {
                 t2c[t] = -2;
             } else {
-                const int64_t id = names_find(&chr_sizes->names, nm);
                 /* generic.c:796-797: cend = size-1 with 2 as the "not found" default; a listed size of 2 reads the same */
-                t2c[t] = (id >= 0 && (int)chr_sizes->value[id] != 2) ? (int32_t)id : -1;
+                t2c[t] = chrom_of_target(aln_target_name(rd, t), o, chr_sizes);
                 if (dups || dd) t2id[t] = names_intern(&chr_names, nm);
             }
         }
@@ -556,6 +679,33 @@ void run_stream(const run_opts *o, const rmsk_t *rm, const sizes_t *chr_sizes, i
          * the window — does a record carry an XA tag (the veto needs its strings: host route for that window), is a mapped
          * record on a chromosome the size file lacks (the warning is per record, in file order: host route). */
         const int handoff_ok = !dups && !bed_f && !bed_uniq_f && !want_qnames;
+        if (drain_backlog) {
+            /* the records the helper thread parsed while the table was being built: first, in file order */
+            const double td = now_s();
+            unsigned long long got = 0;
+            for (size_t k = 0; k < pre_n; k++)
+                for (size_t off = 0; off < pre_v[k].n; off += BATCH_RECORDS) {
+                    const size_t m = pre_v[k].n - off < BATCH_RECORDS ? pre_v[k].n - off : BATCH_RECORDS;
+                    itx_batch db;
+                    chk(itx_backlog_batch(pre_bl, pre_v[k].at + off, pre_v[k].paired, &db), "itx_backlog_batch");
+                    for (unsigned long long mk = (ends / progress_every + 1) * progress_every; mk <= ends + m; mk += progress_every)
+                        fprintf(stderr, "\r* Processed read ends: %llu", mk);
+                    ends += m;
+                    got += m;
+                    chk(itx_engine_submit_device_own(eng, &db, m, NULL), "itx_engine_submit_device_own");
+                }
+            chk(itx_engine_wait_own(eng), "itx_engine_wait_own");
+            if (timing)
+                fprintf(stderr, "\n[itx timing] parsed ahead of the table by the helper thread: %llu records of %zu windows (%.3f s there), submitted in %.3f s\n", got, pre_n,
+                        pre_seconds, now_s() - td);
+        }
+        if (pre_bl && fi == 0 && pass == 0) {                            /* used or not (another share than the plan's): gone */
+            itx_backlog_destroy(pre_bl);
+            pre_bl = NULL;
+            free(pre_v);
+            pre_v = NULL;
+            pre_n = pre_cap = 0;
+        }
         for (;;) {
             if (handoff_ok) {
                 int wfl = 0, direct = 1;

@@ -341,3 +341,29 @@ def test_two_launcher_ranks_meet_in_rccl(exe, big_case, tmp_path):
     assert "exchange (RCCL)" in errs[0], errs[0][-1500:]
     _same_dir(ref_dir, str(tmp_path / "rank0"))
     assert os.listdir(str(tmp_path / "rank1")) == []
+
+
+# ---- records parsed ahead of the table by the helper thread (host/stream.c prefetch_records) ---------------------------------
+@pytest.mark.parametrize("head", [["stat", "-w"], ["filter", "-n", "Rep3"], ["stat", "-w", "-x", "-E", "0"]])
+def test_records_parsed_ahead_of_the_table(head, exe, big_case, tmp_path):
+    """While the rmsk file is parsed and the table built the helper thread parses the decoded windows and keeps their records in a
+    backlog in HBM; run_stream submits the backlog first. Forced here on a small input (ITX_PREFETCH_MIN=0, many small windows,
+    the table "taking" 1.5 s): some windows do go through the backlog, and the files are those of a run without it — single
+    file, file list (only the first file is parsed ahead), and a BAM with XA tags (its windows are left to the loop when the
+    veto is on, taken with -x)."""
+    d = big_case
+    lst = ",".join(str(d / n) for n in ("a.bam", "b.bam"))
+    for aln, what in ((str(d / "a.bam"), "one"), (lst, "list"), (str(d / "xa.bam"), "xa")):
+        if head[0] == "filter" and what == "list":
+            continue
+        plain, ahead = str(tmp_path / f"plain_{what}"), str(tmp_path / f"ahead_{what}")
+        _run(exe, head, d, aln, plain, dict(os.environ, ITX_GPUS="1", ITX_NO_PREFETCH="1"))
+        pr = _run(exe, head, d, aln, ahead, dict(os.environ, ITX_GPUS="1", ITX_TIMING="1", ITX_PREFETCH_MIN="0", ITX_PREFETCH_HOLD_MS="1500", ITX_BGZF_CHUNK="400000"))
+        _same_dir(plain, ahead)
+        import re
+        m = re.search(r"parsed ahead of the table by the helper thread: (\d+) records of (\d+) windows", pr.stderr)
+        veto_keeps_them = what == "xa" and head[0] == "stat" and "-x" not in head
+        if veto_keeps_them:
+            assert m is None or int(m.group(2)) == 0, pr.stderr[-1500:]
+        else:
+            assert m and int(m.group(2)) >= 2 and int(m.group(1)) > 50_000, pr.stderr[-1500:]

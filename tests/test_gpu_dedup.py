@@ -182,3 +182,28 @@ def test_command_equals_the_reference_binary(case, tmp_path):
         for fn in sorted(os.listdir(a)):
             if not fn.endswith(".bigWig"):
                 assert filecmp.cmp(os.path.join(a, fn), os.path.join(b, fn), shallow=False), (what, fn)
+
+
+def test_device_set_with_windows_the_host_has_to_read(case, tmp_path):
+    """A size file that lacks one of the BAM's references: windows with mapped records on it go to the host (the reference warns
+    once per such chromosome, in file order) AFTER the device has marked their duplicates — the marks must survive the fetch and
+    the host's re-parse of the records' strings (-B / -V); same files as with the host's set, and the warning is there."""
+    lib, exe = build.build_all()
+    d = case
+    short = tmp_path / "chrom_short.sizes"
+    short.write_text("".join(ln for ln in open(d / "chrom.sizes") if not ln.startswith("chrM")))
+
+    def run(out, env, opts):
+        os.makedirs(out, exist_ok=True)
+        pr = subprocess.run([exe, "stat", "-w", "-R"] + opts + ["-o", "out", str(short), str(d / "rep.sizes"), str(d / "rmsk.txt"), str(d / "se.bam")], cwd=out,
+                            capture_output=True, text=True, timeout=600, env=env)
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        return pr
+    for opts, what in (([], "plain"), (["-B", "-V"], "bed")):
+        host_dir, dev_dir = str(tmp_path / f"host_{what}"), str(tmp_path / f"dev_{what}")
+        run(host_dir, dict(os.environ, ITX_HOST_DEDUP="1", ITX_GPUS="1"), opts)
+        pr = run(dev_dir, dict(os.environ, ITX_TIMING="1", ITX_GPUS="1", ITX_BGZF_CHUNK="3000000"), opts)
+        assert "-R on the device" in pr.stderr and "chrM not existed in the chromosome size file" in pr.stderr, pr.stderr[-1500:]
+        for fn in sorted(os.listdir(host_dir)):
+            if not fn.endswith(".bigWig"):
+                assert filecmp.cmp(os.path.join(host_dir, fn), os.path.join(dev_dir, fn), shallow=False), (what, fn)

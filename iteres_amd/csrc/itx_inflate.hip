@@ -527,16 +527,80 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
     free(h);
 }
 
+// Page-locked host memory for the reader's chunk buffers. hipHostMalloc of 384 MB takes 62 ms — nearly all of it the kernel
+// handing out and zeroing 98 k small pages, under a lock that other HIP calls of the process wait for; an anonymous mapping the
+// kernel is asked to back with 2 MB pages (the box has transparent huge pages in "madvise" mode), touched once by a few threads
+// and then registered, takes 25 ms single-threaded (touch 24 + hipHostRegister 1; profiles/r03_pin_probe.txt) and copies to
+// the device at the same 57 GB/s. Falls back to hipHostMalloc where any step fails.
+#include <sys/mman.h>
+#include <mutex>
+#include <thread>
+#include <vector>
+struct PinnedMap {
+    void *user, *base;
+    size_t len;
+};
+static std::mutex g_pin_mu;
+static std::vector<PinnedMap> g_pinned;
+
 extern "C" void *itx_pinned_alloc(size_t bytes)
 {
+    if (bytes == 0) bytes = 1;
+    const size_t huge = (size_t)2 << 20;
+    if (bytes >= 4 * huge && !getenv("ITX_PIN_PLAIN")) {
+        const size_t len = ((bytes + huge - 1) & ~(huge - 1)) + huge;
+        struct timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        void *base = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base != MAP_FAILED) {
+            uint8_t *user = (uint8_t *)(((uintptr_t)base + huge - 1) & ~(uintptr_t)(huge - 1));
+            const size_t ulen = (bytes + huge - 1) & ~(huge - 1);
+            (void)madvise(user, ulen, MADV_HUGEPAGE);
+            // first touch (one byte per 2 MB would do for huge pages; every 4 KB page when the kernel declines them)
+            const unsigned nt = 4;
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++)
+                th.emplace_back([=]() {
+                    const size_t lo = ulen / nt * t, hi = t + 1 == nt ? ulen : ulen / nt * (t + 1);
+                    for (size_t a = lo; a < hi; a += 4096) ((volatile uint8_t *)user)[a] = 0;
+                });
+            for (auto &x : th) x.join();
+            struct timespec ta, tb;
+            clock_gettime(CLOCK_MONOTONIC, &ta);
+            const hipError_t re = hipHostRegister(user, ulen, hipHostRegisterDefault);
+            clock_gettime(CLOCK_MONOTONIC, &tb);
+            if (getenv("ITX_TIMING_ALLOC"))
+                fprintf(stderr, "[itx alloc] page-locked %.0f MB: mapped + touched %.1f ms, hipHostRegister %.1f ms\n", (double)ulen / 1e6,
+                        1e3 * ((double)(ta.tv_sec - t0.tv_sec) + 1e-9 * (double)(ta.tv_nsec - t0.tv_nsec)), 1e3 * ((double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec)));
+            if (re == hipSuccess) {
+                std::lock_guard<std::mutex> g(g_pin_mu);
+                g_pinned.push_back(PinnedMap{user, base, len});
+                return user;
+            }
+            (void)hipGetLastError();
+            munmap(base, len);
+        }
+    }
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
     return p;
 }
 
 extern "C" void itx_pinned_free(void *p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        for (size_t i = 0; i < g_pinned.size(); i++)
+            if (g_pinned[i].user == p) {
+                const PinnedMap m = g_pinned[i];
+                g_pinned.erase(g_pinned.begin() + (long)i);
+                (void)hipHostUnregister(m.user);
+                munmap(m.base, m.len);
+                return;
+            }
+    }
+    (void)hipHostFree(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -80,23 +80,27 @@ enum {
 
 // ---------------------------------------------------------------------------------------------------- pass 1: tokens
 
-// One decoder's tables (element i through ITXI_AT), 628 bytes: on the device they live in LDS, a lane's worth per block, and
-// how many blocks pass 1 can hold at once is how much of it fits — 40 KB per wave of 64 blocks, four waves per CU (with
-// 16-bit symbols and a byte per code length it was 68 KB and two).
+// One decoder's tables (element i through ITXI_AT), 420 bytes: on the device they live in LDS, a lane's worth per block, and how
+// many blocks pass 1 can hold at once is how much of it fits — 26.25 KB per wave of 64 blocks, SIX waves per CU (with the code
+// lengths and the counting sort's cursors in arrays of their own it was 40 KB and four; with 16-bit symbols and a byte per code
+// length 68 KB and two). The code lengths being set up (two to a byte: literal/length at 0, distance at 288, code-length code
+// at 320) borrow the symbol table's room from byte ITXI_LENS_AT on — the header is parsed before there are symbols to keep, the
+// code-length code's own 19 symbols sit below — and move to a few words of the block's scratch region before the tables are
+// built from them (itxi_tokens: `stage`).
+#define ITXI_LENS_AT 32u
 struct ItxiTab {
     uint8_t *lsym8;                        // [288]: literal/length symbols in canonical order (by code length, then symbol), low 8 bits
     uint32_t *lhi;                         // [9]:   bit i of the bitmap: the symbol at canonical place i is >= 256
     uint8_t *dsym;                         // [32]:  distance symbols in canonical order
-    uint16_t *offs;                        // [16]:  scratch of the counting sort
-    uint16_t *loffs, *doffs;               // [16] each: itxi_decode's per-length offsets of the two codes in use
-    uint8_t *lens;                         // [176]: code lengths being set up, two to a byte: literal/length at 0, distance at 288, code-length code at 320
+    uint16_t *loffs, *doffs;               // [16] each: itxi_decode's per-length offsets of the two codes in use (the counting sort's cursors meanwhile)
 };
-#define ITXI_LEN_GET(T, i) ((uint32_t)(ITXI_AT((T).lens, (i) >> 1) >> (((i) & 1u) * 4u)) & 15u)
+#define ITXI_LEN_GET(T, i) ((uint32_t)(ITXI_AT((T).lsym8, ITXI_LENS_AT + ((i) >> 1)) >> (((i) & 1u) * 4u)) & 15u)
 #define ITXI_LEN_SET(T, i, v)                                                                                     \
     do {                                                                                                          \
-        const uint32_t i__ = (i), sh__ = (i__ & 1u) * 4u;                                                         \
-        ITXI_AT((T).lens, i__ >> 1) = (uint8_t)((ITXI_AT((T).lens, i__ >> 1) & ~(15u << sh__)) | (((v) & 15u) << sh__)); \
+        const uint32_t i__ = (i), sh__ = (i__ & 1u) * 4u, at__ = ITXI_LENS_AT + (i__ >> 1);                       \
+        ITXI_AT((T).lsym8, at__) = (uint8_t)((ITXI_AT((T).lsym8, at__) & ~(15u << sh__)) | (((v) & 15u) << sh__)); \
     } while (0)
+#define ITXI_STAGE_WORDS 40u               // the code lengths as words, eight to a word (literal/length from word 0, distance from word 36)
 
 struct ItxiCodes {
     // bound l (l = 1..15): every code of length <= l, written MSB first and left-aligned to 15 bits, is below it (the bounds
@@ -257,18 +261,34 @@ ITXI_FN uint32_t itxi_decode(const ItxiCodes &h, const uint16_t *offs, uint32_t 
     return ok ? at : 0u;                                           // a pattern that is no code must not become a table index
 }
 
-// Counting sort of `n` code lengths (T.lens[base ..]) into canonical order (puff.c construct()). Returns 0 for a complete
-// code, > 0 for an incomplete one (bits left over), < 0 for an over-subscribed one.
-ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, bool dist, uint16_t *offs_out, uint32_t base, uint32_t n, uint32_t &n_zero_or_one)
+// eight code lengths (nibbles 8 * widx ..) as one word: from the staged copy, or from where the header parse keeps them
+ITXI_FN uint32_t itxi_lens_word(const ItxiTab &T, uint32_t ln, const uint32_t *stage, uint32_t widx)
+{
+    (void)ln;
+    if (stage) return stage[widx];
+    const uint32_t b = ITXI_LENS_AT + 4u * widx;
+    return (uint32_t)ITXI_AT(T.lsym8, b) | (uint32_t)ITXI_AT(T.lsym8, b + 1u) << 8 | (uint32_t)ITXI_AT(T.lsym8, b + 2u) << 16 | (uint32_t)ITXI_AT(T.lsym8, b + 3u) << 24;
+}
+
+// Counting sort of `n` code lengths (nibbles base .., base a multiple of 8; `stage`: read from there, NULL: from the tables'
+// own room) into canonical order (puff.c construct()). Returns 0 for a complete code, > 0 for an incomplete one (bits left
+// over), < 0 for an over-subscribed one.
+ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, bool dist, uint16_t *offs_out, const uint32_t *stage, uint32_t base, uint32_t n,
+                               uint32_t &n_zero_or_one)
 {
     (void)ln;
     uint32_t cnt[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) cnt[i] = 0;
-    for (uint32_t s = 0; s < n; s++) {
-        const uint32_t l = ITXI_LEN_GET(T, base + s);
+    const uint32_t w0 = base >> 3;
+    for (uint32_t w = 0; 8u * w < n; w++) {
+        const uint32_t word = itxi_lens_word(T, ln, stage, w0 + w);
 #pragma unroll
-        for (int i = 0; i < 16; i++) cnt[i] += (l == (uint32_t)i) ? 1u : 0u;
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t l = 8u * w + k < n ? (word >> (4u * k)) & 15u : 16u;
+#pragma unroll
+            for (int i = 0; i < 16; i++) cnt[i] += (l == (uint32_t)i) ? 1u : 0u;
+        }
     }
     n_zero_or_one = cnt[0] + cnt[1];          // an incomplete code is legal only as ONE code of length 1 (zlib inftrees.c, puff.c)
     int32_t left = 1;
@@ -281,22 +301,26 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, bool
     uint32_t o = 0;
 #pragma unroll
     for (int len = 1; len <= 15; len++) {
-        ITXI_AT(T.offs, len) = (uint16_t)o;
+        ITXI_AT(offs_out, len) = (uint16_t)o;                  // the sort's cursors; the decoder's offsets replace them below
         o += cnt[len];
     }
     if (!dist)
         for (uint32_t k = 0; k < 9; k++) ITXI_AT(T.lhi, k) = 0;
-    for (uint32_t s = 0; s < n; s++) {
-        const uint32_t l = ITXI_LEN_GET(T, base + s);
-        if (l != 0) {
-            const uint32_t at = ITXI_AT(T.offs, l);
-            if (dist) {
-                ITXI_AT(T.dsym, at) = (uint8_t)s;
-            } else {
-                ITXI_AT(T.lsym8, at) = (uint8_t)s;
-                if (s >= 256u) ITXI_AT(T.lhi, at >> 5) |= 1u << (at & 31u);
+    for (uint32_t w = 0; 8u * w < n; w++) {
+        const uint32_t word = itxi_lens_word(T, ln, stage, w0 + w);
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t sy = 8u * w + k;
+            const uint32_t l = sy < n ? (word >> (4u * k)) & 15u : 0u;
+            if (l != 0) {
+                const uint32_t at = ITXI_AT(offs_out, l);
+                if (dist) {
+                    ITXI_AT(T.dsym, at) = (uint8_t)sy;
+                } else {
+                    ITXI_AT(T.lsym8, at) = (uint8_t)sy;
+                    if (sy >= 256u) ITXI_AT(T.lhi, at >> 5) |= 1u << (at & 31u);
+                }
+                ITXI_AT(offs_out, l) = (uint16_t)(at + 1u);
             }
-            ITXI_AT(T.offs, l) = (uint16_t)(at + 1u);
         }
     }
     // what itxi_decode wants: the bounds, and per length (place of its first code) - (its first code), mod 2^16
@@ -395,7 +419,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                 if (itxi_overrun(in)) return ITXI_E_INPUT;
                 ItxiCodes cc;
                 uint32_t n01;
-                if (itxi_construct(T, ln, cc, false, T.loffs, 320, 19, n01) != 0) return ITXI_E_CODES;           // must be complete
+                if (itxi_construct(T, ln, cc, false, T.loffs, nullptr, 320, 19, n01) != 0) return ITXI_E_CODES; // must be complete (its 19 symbols go to lsym8[0, 19): below the lengths)
                 // code lengths of the literal/length and distance codes, run-length coded as ONE sequence (a run may
                 // cross from one code into the other); entry idx of it lives at place(idx)
 #define ITXI_PLACE(i) ((i) < nl ? (i) : 288u + ((i) - nl))
@@ -430,10 +454,16 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
 #undef ITXI_PLACE
                 if (ITXI_LEN_GET(T, 256u) == 0) return ITXI_E_CODES;                             // no end-of-block code
             }
+            // The lengths leave the symbol table's room before the symbols move in: 40 words into the gap of the block's scratch region
+            // between its literals (behind the word the next literals complete) and its tokens — literals + 4 x tokens stay below
+            // 87 382 (ITXI_REGION's comment), the words end at most 179 bytes past the literals: 2.5 KB to spare — and are read back
+            // eight lengths to a word. The next literals write over them.
+            uint32_t *stage = lit32 + (((n_lit + 4u + 15u) & ~15u) >> 2);
+            for (uint32_t w = 0; w < ITXI_STAGE_WORDS; w++) stage[w] = itxi_lens_word(T, ln, nullptr, w);
             uint32_t n01;
-            int32_t left = itxi_construct(T, ln, lc, false, T.loffs, 0, nl, n01);
+            int32_t left = itxi_construct(T, ln, lc, false, T.loffs, stage, 0, nl, n01);
             if (type == 2 && left != 0 && (left < 0 || nl != n01)) return ITXI_E_CODES;          // the fixed code is incomplete by definition
-            left = itxi_construct(T, ln, dc, true, T.doffs, 288, nd, n01);
+            left = itxi_construct(T, ln, dc, true, T.doffs, stage, 288, nd, n01);
             if (type == 2 && left != 0 && (left < 0 || nd != n01)) return ITXI_E_CODES;
 
             for (;;) {                                             // one symbol per turn; each produces output or ends the block

@@ -55,6 +55,9 @@
 #define ITXI_STRIPE 256u                   // write-back granule: 64 lanes x 4 bytes
 #define ITXI_NEAR (ITXI_RING - 320u)       // matches up to this distance read the ring (a match writes at most 258 bytes ahead)
 #define ITXI_LAG 1024u                     // pass 2: full stripes may wait this long for their write-back (+ a stripe + a token < ITXI_NEAR - 258)
+#ifndef ITXI_LITS
+#define ITXI_LITS 2                        // pass 1: literal/length codes a turn may take (itxi_tokens)
+#endif
 #define ITXI_MAX_BLOCK 65536u              // BGZF: a block inflates to at most 64 KiB
 // What pass 1 leaves for pass 2 lives in ONE region of scratch per block: the literal bytes grow up from its bottom, the 4-byte
 // tokens down from its top. A match stands for at least 3 bytes of output and takes 4 bytes of token, a literal takes one, a
@@ -466,21 +469,39 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
             left = itxi_construct(T, ln, dc, true, T.doffs, stage, 288, nd, n01);
             if (type == 2 && left != 0 && (left < 0 || nd != n01)) return ITXI_E_CODES;
 
-            for (;;) {                                             // one symbol per turn; each produces output or ends the block
-                itxi_refill(in);
-                uint32_t cl;
-                uint32_t at = itxi_decode(lc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);
-                if (cl == 0) return ITXI_E_SYMBOL;
-                itxi_bits(in, cl);
-                const uint32_t sym = (uint32_t)ITXI_AT(T.lsym8, at) | (((ITXI_AT(T.lhi, at >> 5) >> (at & 31u)) & 1u) << 8);
+            // A turn: up to ITXI_LITS literal/length codes — the first that is no literal ends them — then, behind a length, its
+            // distance code. A turn costs the wave what its instructions cost whatever a lane finds in it (64 blocks in 64 states:
+            // every branch is taken by some lane), and its fixed part outweighs a decode: most codes are literals, so a second and
+            // third try at one takes turns off every block for a fraction of a turn each.
+            for (;;) {
+                uint32_t cl, at, sym;
+#define ITXI_LITLEN()                                                                                                       \
+    itxi_refill(in);                                                                                                        \
+    at = itxi_decode(lc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);                                                       \
+    if (cl == 0) return ITXI_E_SYMBOL;                                                                                      \
+    itxi_bits(in, cl);                                                                                                      \
+    sym = (uint32_t)ITXI_AT(T.lsym8, at) | (((ITXI_AT(T.lhi, at >> 5) >> (at & 31u)) & 1u) << 8)
+#define ITXI_LITERAL()                                                                                                      \
+    if (itxi_past(in)) return ITXI_E_INPUT; /* literals out of the bytes behind the block: stop before the padding ends */ \
+    if (produced >= usize) return ITXI_E_OUTPUT;                                                                            \
+    ITXI_PUT_LIT(sym);                                                                                                      \
+    run++;                                                                                                                  \
+    produced++
+                ITXI_LITLEN();
+#pragma unroll
+                for (int more = 1; more < ITXI_LITS; more++) {
+                    // ... when at least half of the wave's lanes would use it (blocks that are nearly all matches: legacy content)
+                    if (2u * (uint32_t)__builtin_popcountll(ITXI_BALLOT(sym < 256u)) < (uint32_t)__builtin_popcountll(ITXI_BALLOT(true))) break;
+                    if (sym >= 256u) break;
+                    ITXI_LITERAL();
+                    ITXI_LITLEN();
+                }
                 if (sym < 256u) {
-                    if (itxi_past(in)) return ITXI_E_INPUT;       // literals out of the bytes behind the block: stop before the padding ends
-                    if (produced >= usize) return ITXI_E_OUTPUT;
-                    ITXI_PUT_LIT(sym);
-                    run++;
-                    produced++;
+                    ITXI_LITERAL();
                     continue;
                 }
+#undef ITXI_LITLEN
+#undef ITXI_LITERAL
                 if (sym == 256u) break;
                 const uint32_t li = sym - 257u;
                 if (li >= 29u) return ITXI_E_SYMBOL;

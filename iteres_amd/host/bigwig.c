@@ -498,7 +498,7 @@ static int cmp_chrom_name(const void *a, const void *b)
 /* names[i] / len[i] / val[i]: the wig blocks (only names with len != 0 belong here, generic.c:83-90); a value is the
  * float the converter makes of the wig's text: (float)strtod("%u" or "%.4f" of the number) */
 #include <time.h>
-static double bw_t0;
+static __thread double bw_t0;
 static void bw_tick(const char *what)
 {
     struct timespec ts;

@@ -5,6 +5,7 @@
 
 #include <getopt.h>
 #include <libgen.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -195,8 +196,28 @@ int main_stat(int argc, char **argv)
                 vu[k] = fu + cov_off[i];
                 k++;
             }
-        write_bigwig(outBigWig, outWig, nm, ln, va, k);
-        write_bigwig(outBigWigUniq, outWigUniq, nm, ln, vu, k);
+        /* The two files share nothing but their inputs: each gets half of the threads, and the serial stretches of one (zoom
+         * lists, index, the writes themselves) run beside the other's. ITX_BW_SERIAL=1: one after the other. */
+        if (getenv("ITX_BW_SERIAL") || omp_get_max_threads() < 2) {
+            write_bigwig(outBigWig, outWig, nm, ln, va, k);
+            write_bigwig(outBigWigUniq, outWigUniq, nm, ln, vu, k);
+        } else {
+            const int half = omp_get_max_threads() / 2;
+            omp_set_max_active_levels(2);
+#pragma omp parallel sections num_threads(2)
+            {
+#pragma omp section
+                {
+                    omp_set_num_threads(half);
+                    write_bigwig(outBigWig, outWig, nm, ln, va, k);
+                }
+#pragma omp section
+                {
+                    omp_set_num_threads(half);
+                    write_bigwig(outBigWigUniq, outWigUniq, nm, ln, vu, k);
+                }
+            }
+        }
         free(fa); free(fu);
         free(nm); free(ln); free(va); free(vu);
     }

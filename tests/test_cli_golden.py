@@ -84,3 +84,23 @@ def test_cli_decode_paths_agree(env, exe, tmp_path):
         for fn in run["files"]:
             want = refio.read_bytes(os.path.join(gc.GOLDEN, case, run_name, fn))
             assert (work / fn).read_bytes() == want, f"{env}: {case}/{run_name}/{fn} differs"
+
+
+def test_bigwig_files_written_side_by_side_equal_one_after_the_other(exe, tmp_path):
+    """`stat` writes its two bigWig files at the same time, each with half of the threads (cmd_stat.c); ITX_BW_SERIAL=1 writes
+    them one after the other with all of them: the same bytes either way, and with one thread."""
+    run = gc.manifest_run("mid", "stat_default")
+    src = os.path.join(gc.GOLDEN, "mid", "in")
+    paths = [refio.materialise(src, n, str(tmp_path)) for n in ["chrom.sizes", "rep.sizes", "rmsk.txt", run["aln"]]]
+    seen = {}
+    for name, env in (("side_by_side", {}), ("serial", {"ITX_BW_SERIAL": "1"}), ("one_thread", {"OMP_NUM_THREADS": "1"})):
+        work = tmp_path / name
+        work.mkdir()
+        pr = subprocess.run([exe, run["cmd"]] + run["opts"] + ["-o", run["prefix"]] + paths, cwd=work, capture_output=True, text=True, timeout=600,
+                            env=dict(os.environ, **env))
+        assert pr.returncode == run["rc"], pr.stderr[-2000:]
+        seen[name] = {fn: (work / fn).read_bytes() for fn in run.get("bigwig_sha256", {})}
+        assert seen[name], "the run is expected to write bigWig files"
+        for fn, want in run["bigwig_sha256"].items():
+            assert refio.bigwig_digest(seen[name][fn]) == want, f"{name}: {fn} differs from the reference's"
+    assert seen["side_by_side"] == seen["serial"] == seen["one_thread"]

@@ -87,13 +87,13 @@ def test_cli_decode_paths_agree(env, exe, tmp_path):
 
 
 def test_bigwig_files_written_side_by_side_equal_one_after_the_other(exe, tmp_path):
-    """`stat` writes its two bigWig files at the same time, each with half of the threads (cmd_stat.c); ITX_BW_SERIAL=1 writes
-    them one after the other with all of them: the same bytes either way, and with one thread."""
+    """`stat` writes its two bigWig files one after the other with all of its threads; ITX_BW_PAIR=1 writes them at the same
+    time, each with half of the threads (cmd_stat.c): the same bytes either way, and with one thread."""
     run = gc.manifest_run("mid", "stat_default")
     src = os.path.join(gc.GOLDEN, "mid", "in")
     paths = [refio.materialise(src, n, str(tmp_path)) for n in ["chrom.sizes", "rep.sizes", "rmsk.txt", run["aln"]]]
     seen = {}
-    for name, env in (("side_by_side", {}), ("serial", {"ITX_BW_SERIAL": "1"}), ("one_thread", {"OMP_NUM_THREADS": "1"})):
+    for name, env in (("side_by_side", {"ITX_BW_PAIR": "1"}), ("serial", {}), ("one_thread", {"OMP_NUM_THREADS": "1"})):
         work = tmp_path / name
         work.mkdir()
         pr = subprocess.run([exe, run["cmd"]] + run["opts"] + ["-o", run["prefix"]] + paths, cwd=work, capture_output=True, text=True, timeout=600,

@@ -513,8 +513,10 @@ def main():
         wall_last, err_last, seen = last
         scan_s = seen.get(SCAN_END, 0) - seen.get(SCAN_BEGIN, 0) if SCAN_BEGIN in seen and SCAN_END in seen else None
         phases = [ln for ln in err_last.split("\n") if ln.startswith("[itx timing]")]
-        # "total reads (pair)" (generic.c:53-70) counts first ends: every record of a single-end file, half of them with --paired 1
-        checks = {"report_total_equals_reads": bool(rep and rep[0] == (a.reads * world) // (2 if a.paired else 1)),
+        # "total reads (pair)" (generic.c:53-70) counts first ends: every record of a single-end file; with --paired 1 half of them
+        # plus the odd read a chromosome's segment may end on (tools/mkbam.c), a few thousand at most
+        checks = {"report_total_equals_reads": bool(rep and (rep[0] == a.reads * world if not a.paired
+                                                             else 0 <= rep[0] - (a.reads * world) // 2 <= 4096 * world)),
                   "outputs_written": all(os.path.exists(os.path.join(scratch, fn)) for fn in TEXT_OUTPUTS + ("out.iteres.bigWig", "out.iteres.unique.bigWig"))}
         ms_per_step = elapsed * 1e3 / a.steps
         out = {

@@ -69,11 +69,6 @@ __global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp
     __shared__ uint16_t s_loffs[16 * 64], s_doffs[16 * 64];
     __shared__ uint8_t s_lsym8[288 * 64], s_dsym[32 * 64];
     const uint32_t ln = threadIdx.x, b = blockIdx.x * 64u + ln;
-#ifdef ITX_TOKENS_PRIO
-    // experiment builds: this wave is a long chain of dependent instructions that shares its SIMD with the short-lived waves of
-    // pass 2 and the engine's kernels — let the issue arbiter serve it first
-    __builtin_amdgcn_s_setprio(ITX_TOKENS_PRIO);
-#endif
     if (b >= n) return;
     const uint32_t coff = blk[b].coff, csize = blk[b].csize, usize = blk[b].usize;
     ItxiTab T{s_lsym8, s_lhi, s_dsym, s_loffs, s_doffs};

@@ -353,21 +353,6 @@ static int compute_lanes()
     return v;
 }
 
-// ITX_PASS2_STREAM=1: pass 2 of a push runs on a second stream of its compute lane, so the lane's next pass 1 starts as soon as this
-// one is through (a lane is then busy pass 1 only, not pass 1 + pass 2 + the status copy). The scratch pass 2 reads must then
-// outlive the next pass 1 on the lane: one scratch region per SLOT instead of one per lane (the host waits for a slot's push
-// before it gives the slot another, so nothing else needs ordering).
-static int pass2_own_stream()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("ITX_PASS2_STREAM");
-        v = e && atoi(e) != 0;
-    }
-    return v;
-}
-static int scratch_sets() { return pass2_own_stream() ? lanes_in_use() : compute_lanes(); }
-
 struct itx_inflater {
     int device;
     hipStream_t st[2];
@@ -401,7 +386,7 @@ struct itx_inflater {
     } lane[ITX_BAMWIN_LANES];
     // a compute lane: the stream the two passes of its slots' pushes run on, one after the other, and their scratch
     struct {
-        hipStream_t cst, rst;              // rst: pass 2's own stream (ITX_PASS2_STREAM)
+        hipStream_t cst;
         uint8_t *d_lit;
         uint32_t *d_meta;
         size_t lit_cap, meta_cap;
@@ -461,8 +446,6 @@ extern "C" int itx_inflater_create(int device, itx_inflater **out)
     // after the other — two compute lanes on one queue halved pass 1's overlap (1.8 kernels in flight instead of 3)
     INF_HIP(hipStreamCreateWithFlags(&h->copy_st, hipStreamNonBlocking));
     for (int k = 0; k < compute_lanes(); k++) INF_HIP(hipStreamCreateWithFlags(&h->clane[k].cst, hipStreamNonBlocking));
-    if (pass2_own_stream())
-        for (int k = 0; k < compute_lanes(); k++) INF_HIP(hipStreamCreateWithFlags(&h->clane[k].rst, hipStreamNonBlocking));
     SETUP_TICK("lane streams, events, counters");
     h->n_cu = 256;
     if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
@@ -507,10 +490,6 @@ extern "C" void itx_inflater_destroy(itx_inflater *h)
         if (h->clane[k].cst) {
             (void)hipStreamSynchronize(h->clane[k].cst);
             (void)hipStreamDestroy(h->clane[k].cst);
-        }
-        if (h->clane[k].rst) {
-            (void)hipStreamSynchronize(h->clane[k].rst);
-            (void)hipStreamDestroy(h->clane[k].rst);
         }
         if (!h->arena) {
             (void)hipFree(h->lane[k].d_comp);
@@ -896,13 +875,12 @@ extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *
         Ln.h_blk[i] = blk[i];
         Ln.h_blk[i].uoff += WIN_HEAD;
     }
-    auto &CL = h->clane[s % compute_lanes()];        // the streams ...
-    auto &SC = h->clane[s % scratch_sets()];         // ... and the scratch (the same entry unless pass 2 has a stream of its own)
+    auto &CL = h->clane[s % compute_lanes()];
     if ((rc = grow(&Ln.d_comp, &Ln.comp_cap, comp_len + 64)) != ITX_OK) return rc;
     if ((rc = grow(&Ln.d_status, &Ln.status_cap, n_blk)) != ITX_OK) return rc;
     if ((rc = grow(&Ln.d_blk, &Ln.blk_cap, n_blk)) != ITX_OK) return rc;
-    if ((rc = grow(&SC.d_lit, &SC.lit_cap, n_blk * (size_t)SCR_STRIDE)) != ITX_OK) return rc;      // (growing frees: that waits for whatever still runs)
-    if ((rc = grow(&SC.d_meta, &SC.meta_cap, 3 * n_blk)) != ITX_OK) return rc;
+    if ((rc = grow(&CL.d_lit, &CL.lit_cap, n_blk * (size_t)SCR_STRIDE)) != ITX_OK) return rc;      // (growing frees: that waits for whatever still runs)
+    if ((rc = grow(&CL.d_meta, &CL.meta_cap, 3 * n_blk)) != ITX_OK) return rc;
     // the bytes cross PCIe on the copy stream ...
     INF_HIP(hipMemcpyAsync(Ln.d_blk, Ln.h_blk, n_blk * sizeof *blk, hipMemcpyHostToDevice, h->copy_st));
     INF_HIP(hipMemcpyAsync(Ln.d_comp, comp, comp_len, hipMemcpyHostToDevice, h->copy_st));
@@ -911,18 +889,13 @@ extern "C" int itx_bamwin_push_begin(itx_inflater *h, int w, int s, const void *
     hipStream_t st = CL.cst;
     INF_HIP(hipStreamWaitEvent(st, Ln.copied, 0));
     INF_HIP(hipEventRecord(Ln.ev[0], st));
-    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, SC.d_lit, SC.d_meta);
+    hipLaunchKernelGGL(k_tokens, dim3((unsigned)((n_blk + 63) / 64)), dim3(64), 0, st, (const uint32_t *)Ln.d_comp, Ln.d_blk, (uint32_t)n_blk, CL.d_lit, CL.d_meta);
     INF_HIP(hipGetLastError());
     // pass 2 on the same stream, one wave per block (every push's pass 2 on one shared stream, or a fixed set of waves
-    // that take blocks in turn, were measured slower: DESIGN.md) — or on the lane's second stream (ITX_PASS2_STREAM)
+    // that take blocks in turn, were measured slower: DESIGN.md)
     hipStream_t sr = st;
-    INF_HIP(hipEventRecord(Ln.ev[1], st));
-    if (pass2_own_stream()) {
-        INF_HIP(hipEventRecord(Ln.p1_done, st));
-        sr = CL.rst;
-        INF_HIP(hipStreamWaitEvent(sr, Ln.p1_done, 0));       // (the "pass 2" time of ITX_TIMING then holds its wait for the push before it on rst)
-    }
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, sr, Ln.d_blk, 0u, (uint32_t)n_blk, SC.d_lit, SC.d_meta, h->win[w].buf, Ln.d_status);
+    INF_HIP(hipEventRecord(Ln.ev[1], sr));
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)n_blk), dim3(64), 0, sr, Ln.d_blk, 0u, (uint32_t)n_blk, CL.d_lit, CL.d_meta, h->win[w].buf, Ln.d_status);
     INF_HIP(hipGetLastError());
     INF_HIP(hipEventRecord(Ln.ev[2], sr));
     INF_HIP(hipMemcpyAsync(Ln.h_status, Ln.d_status, n_blk, hipMemcpyDeviceToHost, sr));
@@ -989,7 +962,8 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t sz_comp = al(comp_bytes + 64), sz_status = al(max_blocks), sz_blk = al(max_blocks * sizeof(itx_bgzf_block)), sz_lit = al(max_blocks * (size_t)SCR_STRIDE),
                  sz_meta = al(3 * max_blocks * 4);
-    const size_t total = (sz_comp + sz_status + sz_blk) * (size_t)n_lanes + (sz_lit + sz_meta) * (size_t)scratch_sets() + per * n;
+    const int n_comp = compute_lanes();
+    const size_t total = (sz_comp + sz_status + sz_blk) * (size_t)n_lanes + (sz_lit + sz_meta) * (size_t)n_comp + per * n;
     uint8_t *base = nullptr;
     const double t0 = wall_now();
     hipError_t he = hipMalloc((void **)&base, total);
@@ -1018,7 +992,7 @@ extern "C" int itx_inflater_reserve(itx_inflater *h, size_t comp_bytes, size_t m
             Ln.h_cap = max_blocks + 64;
         }
     }
-    for (int k = 0; k < scratch_sets(); k++) {
+    for (int k = 0; k < n_comp; k++) {
         auto &CL = h->clane[k];
         CL.d_lit = p; p += sz_lit; CL.lit_cap = max_blocks * (size_t)SCR_STRIDE;
         CL.d_meta = (uint32_t *)p; p += sz_meta; CL.meta_cap = 3 * max_blocks;

@@ -247,4 +247,9 @@ void write_cpg_loci(const rmsk_t *rm, const int *cpg_count, const double *cpg_to
 
 int main_stat(int argc, char **argv);
 int main_filter(int argc, char **argv);
+/* numa.c */
+void numa_place(void);              /* at program start, before any thread: ITX_CPUS, else the processors of the GPU's memory node (ITX_NUMA=0: no) */
+void numa_spawn_begin(void);        /* around the start of another rank: it inherits the affinity the process was started with */
+void numa_spawn_end(void);
+
 #endif

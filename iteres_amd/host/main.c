@@ -26,6 +26,7 @@ static int usage(void)
 int main(int argc, char *argv[])
 {
     if (argc < 2) return usage();
+    numa_place();
     struct timespec ts_main0;
     clock_gettime(CLOCK_MONOTONIC, &ts_main0);
     /* The HIP runtime multiplexes its streams onto 4 hardware queues by default, and kernels that share a hardware queue run

@@ -254,7 +254,9 @@ void multi_begin(int splittable, const char *aln_arg, int multi_file)
         for (int j = 0; j < 5; j++) env[k++] = v[j];
         env[k] = NULL;
         pid_t pid = 0;
+        numa_spawn_begin();
         const int rc = posix_spawn(&pid, "/proc/self/exe", NULL, NULL, g_argv, env);
+        numa_spawn_end();
         free(env);
         if (rc != 0) {
             kill_kids();

@@ -63,7 +63,7 @@ static int gpu_memory_node(int device)
             else if (!strncmp(line, "drm_render_minor ", 17)) minor = atol(line + 17);
         }
         fclose(f);
-        if (simd <= 0 || minor < 0) continue;                      /* a CPU node */
+        if (simd <= 0 || minor < 0) continue;                      /* a CPU node, or another tenant's GPU (its properties do not read) */
         snprintf(path, sizeof path, "/dev/dri/renderD%ld", minor);
         const int fd = open(path, O_RDWR | O_CLOEXEC);            /* (open, not access: a device cgroup says no only here) */
         if (fd < 0) continue;                                      /* another tenant's */

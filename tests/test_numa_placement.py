@@ -56,7 +56,10 @@ def _gpu_node_cpus():
     """the node of the first GPU this process may open, by the same files numa.c reads"""
     base = "/sys/class/kfd/kfd/topology/nodes"
     for k in sorted(int(x) for x in os.listdir(base)):
-        props = dict(ln.split()[:2] for ln in open(f"{base}/{k}/properties") if len(ln.split()) >= 2)
+        try:
+            props = dict(ln.split()[:2] for ln in open(f"{base}/{k}/properties") if len(ln.split()) >= 2)
+        except OSError:                 # another tenant's GPU: the driver does not let us read it
+            continue
         if int(props.get("simd_count", 0)) <= 0 or "drm_render_minor" not in props:
             continue
         minor = int(props["drm_render_minor"])

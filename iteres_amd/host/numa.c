@@ -47,16 +47,21 @@ static int cpus_from_env(void)
 
 /* The memory node the GPU this process will use hangs off, found without starting the runtime: the KFD topology lists the
  * GPUs in the runtime's order with their render minors; the ones whose render node this process may open are its devices.
- * -1: unknown (no such file, one node, a *_VISIBLE_DEVICES list that renumbers the devices). */
+ * -1: unknown (no such files, or a *_VISIBLE_DEVICES list that renumbers several devices). */
 static int gpu_memory_node(int device)
 {
-    if (getenv("HIP_VISIBLE_DEVICES") || getenv("ROCR_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES")) return -1;
-    int seen = 0;
-    for (int k = 0; k < 256; k++) {
+    /* a *_VISIBLE_DEVICES list renumbers the devices: then only a process with ONE GPU to its name knows which one it means */
+    const int renumbered = getenv("HIP_VISIBLE_DEVICES") || getenv("ROCR_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES");
+    long minors[64];
+    int n = 0;
+    for (int k = 0; k < 256 && n < 64; k++) {
         char path[128], line[256];
         snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", k);
         FILE *f = fopen(path, "r");
-        if (!f) break;
+        if (!f) {
+            if (k < 2) continue;                                   /* (node numbers start at 0) */
+            break;
+        }
         long simd = 0, minor = -1;
         while (fgets(line, sizeof line, f)) {
             if (!strncmp(line, "simd_count ", 11)) simd = atol(line + 11);
@@ -68,16 +73,19 @@ static int gpu_memory_node(int device)
         const int fd = open(path, O_RDWR | O_CLOEXEC);            /* (open, not access: a device cgroup says no only here) */
         if (fd < 0) continue;                                      /* another tenant's */
         close(fd);
-        if (seen++ != device) continue;
-        snprintf(path, sizeof path, "/sys/class/drm/renderD%ld/device/numa_node", minor);
-        f = fopen(path, "r");
-        if (!f) return -1;
-        int node = -1;
-        if (fscanf(f, "%d", &node) != 1) node = -1;
-        fclose(f);
-        return node;
+        minors[n++] = minor;
     }
-    return -1;
+    if (n == 0 || (renumbered && n != 1)) return -1;
+    if (renumbered) device = 0;
+    if (device < 0 || device >= n) return -1;
+    char path[128];
+    snprintf(path, sizeof path, "/sys/class/drm/renderD%ld/device/numa_node", minors[device]);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
 }
 
 /* Every thread of the process on the processors of that node (ITX_NUMA=0: wherever the scheduler likes, as before): the

@@ -45,7 +45,7 @@ def test_itx_cpus_is_obeyed(exe_cpu):
     assert n == len(allowed)
 
 
-def test_switched_off_or_renumbered_devices_leave_the_affinity_alone(exe_cpu):
+def test_switched_off_or_no_gpu_leaves_the_affinity_alone(exe_cpu):
     allowed = sorted(os.sched_getaffinity(0))
     for env in ({"ITX_NUMA": "0"}, {"HIP_VISIBLE_DEVICES": "0"}):
         how, n, lo, hi = _report(exe_cpu, env)

@@ -5,10 +5,10 @@ O=$PWD/gpurun_out/r3ad
 mkdir -p $O
 export OMP_NUM_THREADS=16
 python -c "import __graft_entry__ as g; g.build()" > $O/build.txt 2>&1
+ls /dev/dri/ | tr '\n' ' '; echo
+env | grep VISIBLE_DEVICES; ITX_NUMA_REPORT=1 iteres_amd/host/iteres stat 2>&1 | grep "itx numa"
 timeout -k 10 300 python -m pytest tests/test_numa_placement.py -x -q -rs > $O/pytest.txt 2>&1 || { tail -20 $O/pytest.txt; exit 1; }
 tail -4 $O/pytest.txt
-ls /dev/dri/ | tr '\n' ' '; echo
-ITX_NUMA_REPORT=1 iteres_amd/host/iteres stat 2>&1 | head -1
 ITX_AB_MKBAM="content=hiseq cigar=mixed" timeout -k 10 900 python tools/ab_cli.py 500000000 100 6 \
   free:ITX_NUMA=0 \
   > $O/cli_hiseq_500M.json 2> $O/cli_hiseq_500M.err

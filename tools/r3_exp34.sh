@@ -7,6 +7,8 @@ O=$PWD/gpurun_out/r3ww
 mkdir -p $O
 export OMP_NUM_THREADS=16
 python -c "import __graft_entry__ as g; g.build()" > $O/build.txt 2>&1
+# the one-code library, a copy of the engine with only the decoder compiled differently
+[ -f tools/var_lits1/libiteres_amd.so ] || { bash tools/build_inflate_variant.sh lits1 -DITXI_LITS=1 >> $O/build.txt 2>&1 && mkdir -p tools/var_lits1 && cp tools/lits1.so tools/var_lits1/libiteres_amd.so; }
 ITX_AB_MKBAM="content=hiseq cigar=mixed" timeout -k 10 900 python tools/ab_cli.py 500000000 100 6 \
   one_code:LD_LIBRARY_PATH=tools/var_lits1 \
   > $O/cli_hiseq_500M.json 2> $O/cli_hiseq_500M.err

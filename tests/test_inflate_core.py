@@ -14,11 +14,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-# both input forms of pass 1: one word of look-ahead (the device build's, -DITXI_SIMPLE_IN) and the 16-byte read-ahead FIFO
-INPUT_FORMS = [["-DITXI_SIMPLE_IN"], []]
+# both input forms of pass 1: one word of look-ahead (-DITXI_SIMPLE_IN) and the 16-byte read-ahead FIFO (the build's); and
+# the loop taking one or three literal/length codes per turn instead of the build's two (ITXI_LITS)
+INPUT_FORMS = [["-DITXI_SIMPLE_IN"], [], ["-DITXI_LITS=1"], ["-DITXI_LITS=3"]]
 
 
-@pytest.fixture(scope="module", params=INPUT_FORMS, ids=["word_ahead", "fifo"])
+FORM_IDS = ["word_ahead", "fifo", "one_code_per_turn", "three_codes_per_turn"]
+
+
+@pytest.fixture(scope="module", params=INPUT_FORMS, ids=FORM_IDS)
 def lib(request, tmp_path_factory):
     so = str(tmp_path_factory.mktemp("inflate") / "libinflate_host.so")
     subprocess.check_call(["g++", "-O2", "-g", "-shared", "-fPIC", "-Wno-unknown-pragmas"] + request.param + ["-o", so, os.path.join(ROOT, "tests", "inflate_host.cpp")])
@@ -133,7 +137,7 @@ def _fnv(b):
     return h
 
 
-@pytest.mark.parametrize("form", INPUT_FORMS, ids=["word_ahead", "fifo"])
+@pytest.mark.parametrize("form", INPUT_FORMS, ids=FORM_IDS)
 def test_address_sanitizer_exact_buffers(form, tmp_path):
     """The same decoder under -fsanitize=address,undefined with EXACT-size buffers (input: the block + its 8-byte trailer + the
     16 bytes of padding the C ABI asks for; output: usize bytes). Covers what a fuzz without a sanitizer cannot see: reads

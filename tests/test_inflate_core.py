@@ -190,3 +190,75 @@ def test_address_sanitizer_exact_buffers(form, tmp_path):
             assert int(rc) != 0
         elif want is not False:
             assert int(rc) == 0 and int(h) == _fnv(want)
+
+
+class _Bits:
+    """DEFLATE's bit order: fields LSB first, Huffman codes MSB first"""
+
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def field(self, v, n):
+        self.acc |= v << self.n
+        self.n += n
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, c, n):
+        self.field(int(format(c, f"0{n}b")[::-1], 2), n)
+
+    def fixed_sym(self, s):                                      # RFC 1951 3.2.6
+        if s < 144: self.code(0x30 + s, 8)
+        elif s < 256: self.code(0x190 + s - 144, 9)
+        elif s < 280: self.code(s - 256, 7)
+        else: self.code(0xC0 + s - 280, 8)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+        return bytes(self.out)
+
+
+def test_code_lengths_staged_in_the_fullest_scratch_region(lib):
+    """Pass 1 parks the code lengths of a block in the gap between the scratch region's literals and tokens while it builds the
+    tables (itxi_tokens: `stage`). The gap is narrowest when a SECOND block's header is parsed behind a first block of nothing
+    but three-byte matches (4 bytes of token per 3 of output), and the literal word in the making must survive it: hand-made
+    streams, since no compressor writes them."""
+    # (a) 'a', 21 800 matches of (3, distance 1), then a second fixed block of literals and a match reaching far back
+    b = _Bits()
+    b.field(0, 1); b.field(1, 2)
+    b.fixed_sym(ord("a"))
+    for _ in range(21800):
+        b.fixed_sym(257)            # length 3
+        b.code(0, 5)                # distance 1
+    b.fixed_sym(256)
+    b.field(1, 1); b.field(1, 2)
+    for ch in b"bcd":
+        b.fixed_sym(ch)
+    b.fixed_sym(257); b.code(0, 5)  # ddd
+    b.fixed_sym(256)
+    comp = b.done()
+    want = zlib.decompress(comp, -15)
+    assert len(want) == 1 + 3 * 21800 + 3 + 3 and want.endswith(b"abcdddd")
+    rc, got = run(lib, comp, len(want))
+    assert rc == 0 and got == want
+    # (b) 65 001 literals (one byte into a literal word), then a second block: the staged lengths start behind that word
+    rng = np.random.default_rng(11)
+    lits = bytes(rng.integers(0, 256, 65001, dtype=np.uint8))
+    b = _Bits()
+    b.field(0, 1); b.field(1, 2)
+    for ch in lits:
+        b.fixed_sym(ch)
+    b.fixed_sym(256)
+    b.field(1, 1); b.field(1, 2)
+    for ch in b"xyz":
+        b.fixed_sym(ch)
+    b.fixed_sym(285); b.code(29, 5); b.field(8191, 13)          # length 258 from distance 32 768
+    b.fixed_sym(256)
+    comp = b.done()
+    want = zlib.decompress(comp, -15)
+    assert len(want) == 65001 + 3 + 258
+    rc, got = run(lib, comp, len(want))
+    assert rc == 0 and got == want

@@ -65,13 +65,22 @@ static __device__ inline uint32_t itxi_pksign16(uint32_t a, uint32_t b)
 __global__ __launch_bounds__(64) void k_tokens(const uint32_t *__restrict__ comp, const itx_bgzf_block *__restrict__ blk, uint32_t n, uint8_t *__restrict__ scr,
                                                uint32_t *__restrict__ meta)
 {
+#ifndef ITXI_SYM16
     __shared__ uint32_t s_lhi[9 * 64];                                   // 26 880 bytes in all: six of these workgroups to a CU
     __shared__ uint16_t s_loffs[16 * 64], s_doffs[16 * 64];
     __shared__ uint8_t s_lsym8[288 * 64], s_dsym[32 * 64];
+#else
+    __shared__ uint16_t s_lsym16[288 * 64], s_loffs[16 * 64], s_doffs[16 * 64];      // 43 008 bytes: three to a CU (experiment builds)
+    __shared__ uint8_t s_dsym[32 * 64];
+#endif
     const uint32_t ln = threadIdx.x, b = blockIdx.x * 64u + ln;
     if (b >= n) return;
     const uint32_t coff = blk[b].coff, csize = blk[b].csize, usize = blk[b].usize;
+#ifndef ITXI_SYM16
     ItxiTab T{s_lsym8, s_lhi, s_dsym, s_loffs, s_doffs};
+#else
+    ItxiTab T{s_lsym16, s_dsym, s_loffs, s_doffs};
+#endif
     uint8_t *region = scr + (size_t)b * SCR_STRIDE;
     ItxiTokens K{region, reinterpret_cast<uint32_t *>(region + SCR_STRIDE), 0, 0};
     int rc = ITXI_E_INPUT;

@@ -91,6 +91,7 @@ enum {
 // code-length code's own 19 symbols sit below — and move to a few words of the block's scratch region before the tables are
 // built from them (itxi_tokens: `stage`).
 #define ITXI_LENS_AT 32u
+#ifndef ITXI_SYM16
 struct ItxiTab {
     uint8_t *lsym8;                        // [288]: literal/length symbols in canonical order (by code length, then symbol), low 8 bits
     uint32_t *lhi;                         // [9]:   bit i of the bitmap: the symbol at canonical place i is >= 256
@@ -103,6 +104,37 @@ struct ItxiTab {
         const uint32_t i__ = (i), sh__ = (i__ & 1u) * 4u, at__ = ITXI_LENS_AT + (i__ >> 1);                       \
         ITXI_AT((T).lsym8, at__) = (uint8_t)((ITXI_AT((T).lsym8, at__) & ~(15u << sh__)) | (((v) & 15u) << sh__)); \
     } while (0)
+#define ITXI_LSYM_PUT(T, at, sy)                                                    \
+    do {                                                                            \
+        ITXI_AT((T).lsym8, (at)) = (uint8_t)(sy);                                   \
+        if ((sy) >= 256u) ITXI_AT((T).lhi, (at) >> 5) |= 1u << ((at) & 31u);        \
+    } while (0)
+#define ITXI_LSYM_GET(T, at) ((uint32_t)ITXI_AT((T).lsym8, (at)) | (((ITXI_AT((T).lhi, (at) >> 5) >> ((at) & 31u)) & 1u) << 8))
+#define ITXI_LSYM_GET_LOW(T, at) ((uint32_t)ITXI_AT((T).lsym8, (at)))      // a symbol known to be below 256 (the code-length code's)
+#define ITXI_LSYM_CLEAR(T)                                            \
+    do {                                                              \
+        for (uint32_t k__ = 0; k__ < 9; k__++) ITXI_AT((T).lhi, k__) = 0; \
+    } while (0)
+#else
+// Experiment builds (-DITXI_SYM16): the literal/length symbols as ONE 16-bit table — a symbol costs one LDS read instead of two
+// (its low byte and its ninth bit), the tables 43 KB per wave instead of 26 (three waves to a CU). The code lengths being set up
+// lie four to an element from element ITXI_LENS_AT on.
+struct ItxiTab {
+    uint16_t *lsym16;                      // [288]: literal/length symbols in canonical order
+    uint8_t *dsym;
+    uint16_t *loffs, *doffs;
+};
+#define ITXI_LEN_GET(T, i) ((uint32_t)(ITXI_AT((T).lsym16, ITXI_LENS_AT + ((i) >> 2)) >> (((i) & 3u) * 4u)) & 15u)
+#define ITXI_LEN_SET(T, i, v)                                                                                         \
+    do {                                                                                                              \
+        const uint32_t i__ = (i), sh__ = (i__ & 3u) * 4u, at__ = ITXI_LENS_AT + (i__ >> 2);                           \
+        ITXI_AT((T).lsym16, at__) = (uint16_t)((ITXI_AT((T).lsym16, at__) & ~(15u << sh__)) | (((v) & 15u) << sh__)); \
+    } while (0)
+#define ITXI_LSYM_PUT(T, at, sy) (ITXI_AT((T).lsym16, (at)) = (uint16_t)(sy))
+#define ITXI_LSYM_GET(T, at) ((uint32_t)ITXI_AT((T).lsym16, (at)))
+#define ITXI_LSYM_GET_LOW(T, at) ((uint32_t)ITXI_AT((T).lsym16, (at)))
+#define ITXI_LSYM_CLEAR(T) ((void)0)
+#endif
 #define ITXI_STAGE_WORDS 40u               // the code lengths as words, eight to a word (literal/length from word 0, distance from word 36)
 
 struct ItxiCodes {
@@ -269,8 +301,13 @@ ITXI_FN uint32_t itxi_lens_word(const ItxiTab &T, uint32_t ln, const uint32_t *s
 {
     (void)ln;
     if (stage) return stage[widx];
+#ifndef ITXI_SYM16
     const uint32_t b = ITXI_LENS_AT + 4u * widx;
     return (uint32_t)ITXI_AT(T.lsym8, b) | (uint32_t)ITXI_AT(T.lsym8, b + 1u) << 8 | (uint32_t)ITXI_AT(T.lsym8, b + 2u) << 16 | (uint32_t)ITXI_AT(T.lsym8, b + 3u) << 24;
+#else
+    const uint32_t b = ITXI_LENS_AT + 2u * widx;
+    return (uint32_t)ITXI_AT(T.lsym16, b) | (uint32_t)ITXI_AT(T.lsym16, b + 1u) << 16;
+#endif
 }
 
 // Counting sort of `n` code lengths (nibbles base .., base a multiple of 8; `stage`: read from there, NULL: from the tables'
@@ -307,8 +344,7 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, bool
         ITXI_AT(offs_out, len) = (uint16_t)o;                  // the sort's cursors; the decoder's offsets replace them below
         o += cnt[len];
     }
-    if (!dist)
-        for (uint32_t k = 0; k < 9; k++) ITXI_AT(T.lhi, k) = 0;
+    if (!dist) ITXI_LSYM_CLEAR(T);
     for (uint32_t w = 0; 8u * w < n; w++) {
         const uint32_t word = itxi_lens_word(T, ln, stage, w0 + w);
         for (uint32_t k = 0; k < 8; k++) {
@@ -319,8 +355,7 @@ ITXI_FN int32_t itxi_construct(const ItxiTab &T, uint32_t ln, ItxiCodes &h, bool
                 if (dist) {
                     ITXI_AT(T.dsym, at) = (uint8_t)sy;
                 } else {
-                    ITXI_AT(T.lsym8, at) = (uint8_t)sy;
-                    if (sy >= 256u) ITXI_AT(T.lhi, at >> 5) |= 1u << (at & 31u);
+                    ITXI_LSYM_PUT(T, at, sy);
                 }
                 ITXI_AT(offs_out, l) = (uint16_t)(at + 1u);
             }
@@ -433,7 +468,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
                     const uint32_t at = itxi_decode(cc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);
                     if (cl == 0) return ITXI_E_SYMBOL;
                     itxi_bits(in, cl);
-                    const uint32_t sym = ITXI_AT(T.lsym8, at);
+                    const uint32_t sym = ITXI_LSYM_GET_LOW(T, at);
                     if (sym < 16) {
                         ITXI_LEN_SET(T, ITXI_PLACE(idx), sym);
                         idx++;
@@ -480,7 +515,7 @@ ITXI_FN int itxi_tokens(const ItxiTab &T, uint32_t ln, const uint32_t *comp_word
     at = itxi_decode(lc, T.loffs, ln, (uint32_t)in.bb & 0x7fffu, cl);                                                       \
     if (cl == 0) return ITXI_E_SYMBOL;                                                                                      \
     itxi_bits(in, cl);                                                                                                      \
-    sym = (uint32_t)ITXI_AT(T.lsym8, at) | (((ITXI_AT(T.lhi, at >> 5) >> (at & 31u)) & 1u) << 8)
+    sym = ITXI_LSYM_GET(T, at)
 #define ITXI_LITERAL()                                                                                                      \
     if (itxi_past(in)) return ITXI_E_INPUT; /* literals out of the bytes behind the block: stop before the padding ends */ \
     if (produced >= usize) return ITXI_E_OUTPUT;                                                                            \

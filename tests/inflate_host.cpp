@@ -38,8 +38,13 @@ extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, u
                                 uint32_t *n_lit, uint32_t *n_tok)
 {
     static thread_local uint16_t loffs[16], doffs[16];
+#ifndef ITXI_SYM16
     static thread_local uint8_t lsym8[288], dsym[32];
     static thread_local uint32_t lhi[9];
+#else
+    static thread_local uint16_t lsym16[288];
+    static thread_local uint8_t dsym[32];
+#endif
     static thread_local uint32_t mem32[(ITXI_RING + ITXI_LSTAGE + ITXI_BMAP / 8 + 8) / 4];       // the literal stage right behind the ring (itxi_resolve's contract), then the bitmap
     uint32_t *ring32 = mem32, *stage32 = mem32 + ITXI_RING / 4, *bmap32 = mem32 + (ITXI_RING + ITXI_LSTAGE) / 4;
     // the block's scratch region: literals from its bottom, tokens from its top; guard words either side catch a writer that leaves it
@@ -49,7 +54,11 @@ extern "C" int itx_inflate_host(const uint32_t *comp_words, uint32_t data_pos, u
     uint8_t *lit = reinterpret_cast<uint8_t *>(region32.data() + 4);
     uint32_t *tok_top = region32.data() + 4 + ITXI_REGION / 4;
     if (usize > ITXI_MAX_BLOCK) return ITXI_E_OUTPUT;
+#ifndef ITXI_SYM16
     ItxiTab T{lsym8, lhi, dsym, loffs, doffs};
+#else
+    ItxiTab T{lsym16, dsym, loffs, doffs};
+#endif
     ItxiTokens K{lit, tok_top, 0, 0};
     int rc = itxi_tokens(T, 0, comp_words, data_pos, data_end, usize, K);
     if (n_lit) *n_lit = K.n_lit;

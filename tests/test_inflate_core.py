@@ -15,11 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # both input forms of pass 1: one word of look-ahead (-DITXI_SIMPLE_IN) and the 16-byte read-ahead FIFO (the build's); and
-# the loop taking one or three literal/length codes per turn instead of the build's two (ITXI_LITS)
-INPUT_FORMS = [["-DITXI_SIMPLE_IN"], [], ["-DITXI_LITS=1"], ["-DITXI_LITS=3"]]
+# the loop taking one or three literal/length codes per turn instead of the build's two (ITXI_LITS); the experiment build with
+# one 16-bit symbol table (ITXI_SYM16)
+INPUT_FORMS = [["-DITXI_SIMPLE_IN"], [], ["-DITXI_LITS=1"], ["-DITXI_LITS=3"], ["-DITXI_SYM16"]]
 
 
-FORM_IDS = ["word_ahead", "fifo", "one_code_per_turn", "three_codes_per_turn"]
+FORM_IDS = ["word_ahead", "fifo", "one_code_per_turn", "three_codes_per_turn", "symbols_16_bit"]
 
 
 @pytest.fixture(scope="module", params=INPUT_FORMS, ids=FORM_IDS)
